@@ -1,0 +1,187 @@
+/*
+ * ekpnp.h — C ABI of the MI355X-native EK-PNP hot path.
+ *
+ * This header is the drop-in boundary for the reference's host step API
+ * (gyf135/EK-PNP-3D, prototypes LBM.h:159-180, called from main.cu:163-198).
+ * Every entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are raw host or device pointers
+ *   - every call returns an int status (EKPNP_OK == 0); the message of the last
+ *     failure is available through ekpnp_last_error(); nothing ever calls exit()
+ *     (the reference prints and exit()s: LBM.cu:35-53, LBM.h:187-208)
+ *   - a context owns all device memory, FFT plans, streams and events; there are
+ *     no globals (the reference keeps global device pointers, LBM.h:131-142)
+ *   - macroscopic fields use the reference scalar layout [NZ][NY][NX], x fastest
+ *     (LBM.cu:22-25); the population layout is private to the implementation
+ *   - every call is complete-on-return with respect to the context's stream
+ *     unless stated otherwise (ekpnp_step / ekpnp_stream_collide_save /
+ *     ekpnp_fast_poisson only enqueue; ekpnp_synchronize waits)
+ */
+#ifndef EKPNP_H
+#define EKPNP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EKPNP_OK 0
+#define EKPNP_ERR_INVALID 1   /* bad argument / bad state                     */
+#define EKPNP_ERR_HIP 2       /* a HIP runtime call failed                    */
+#define EKPNP_ERR_FFT 3       /* a hipFFT call failed                         */
+#define EKPNP_ERR_NOMEM 4     /* device allocation failed                     */
+
+/* Macroscopic field ids, in the argument order of the reference's
+ * initialization(r, c, cn, fi, u, v, w, ex, ey, ez, temp) (LBM.h:159). */
+enum {
+  EKPNP_RHO = 0,
+  EKPNP_C = 1,   /* cation concentration  (charge_gpu)  */
+  EKPNP_CN = 2,  /* anion concentration   (chargen_gpu) */
+  EKPNP_PHI = 3,
+  EKPNP_UX = 4,
+  EKPNP_UY = 5,
+  EKPNP_UZ = 6,
+  EKPNP_EX = 7,
+  EKPNP_EY = 8,
+  EKPNP_EZ = 9,
+  EKPNP_T = 10,
+  EKPNP_NFIELDS = 11
+};
+
+/* Runtime replacement of the compile-time grid and the __constant__/__device__
+ * physics globals of LBM.h:29-118 (set at main.cu:23-35). */
+typedef struct ekpnp_params {
+  int32_t nx, ny, nz;       /* global lattice, LBM.h:32-35                      */
+  int32_t n_lattices;       /* 4: f,h,hn,temp (reference). 3: f,h,hn (parity-   */
+                            /* safe iff Ra == 0). 1: f only (iff chargeinf==0   */
+                            /* and Ra == 0)                                     */
+  int32_t pb_iterations;    /* Poisson-Boltzmann sweeps in initialization();    */
+                            /* the reference loops i = 0..500 -> 501            */
+  int32_t reserved0;
+  double Lx, Ly, Lz;        /* LBM.h:40-42; Lx=nx*dx, Ly=ny*dy, Lz=(nz-1)*dz    */
+  double dx, dy, dz;        /* LBM.h:43-45                                      */
+  double CFL;               /* LBM.h:51                                         */
+  double dt;                /* LBM.h:52                                         */
+  double cs_square;         /* LBM.h:53  = 1/3/CFL^2                            */
+  double rho0;              /* LBM.h:54                                         */
+  double chargeinf;         /* LBM.h:56                                         */
+  double voltage, voltage2; /* LBM.h:60,62                                      */
+  double Ext;               /* LBM.h:64                                         */
+  double eps;               /* LBM.h:65                                         */
+  double diffu, diffun;     /* LBM.h:66,73                                      */
+  double nu;                /* LBM.h:67-68                                      */
+  double K, Kn;             /* LBM.h:69-70,75-76                                */
+  double D, Ra, TH;         /* LBM.h:97-99                                      */
+  double uw, exf;           /* LBM.h:47-50                                      */
+  double kB, electron, roomT;   /* LBM.h:87-89                                  */
+  double convertCtoCharge;  /* LBM.h:90                                         */
+  double PB_omega;          /* LBM.h:91                                         */
+  double V, VC, VCn, VT;    /* TRT magic numbers, LBM.h:115-118                 */
+} ekpnp_params;
+
+typedef struct ekpnp_ctx ekpnp_ctx;
+
+/* Fill *p with the reference's defaults (LBM.h:29-118) for an nx*ny*nz lattice
+ * with dx=dy=dz=1e-8, Lx=nx*dx, Ly=ny*dy, Lz=(nz-1)*dz. */
+int ekpnp_default_params(ekpnp_params* p, int nx, int ny, int nz);
+
+/* Replaces main.cu:58-152 (device selection, the 13+11+3 cudaMallocs, the cuFFT
+ * plan and the wavenumber tables) for a whole lattice on the current device. */
+int ekpnp_create(const ekpnp_params* p, ekpnp_ctx** out);
+
+/* z-slab variant (no reference counterpart): rank `rank` of
+ * `nranks` owns planes [rank*nz/nranks, (rank+1)*nz/nranks).  nz % nranks must
+ * be 0 and every slab needs >= 4 planes.  Halo transport is the caller's job,
+ * through ekpnp_halo_* below. */
+int ekpnp_create_slab(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** out);
+
+/* Replaces main.cu:264-290 (cudaFree / cufftDestroy / cudaDeviceReset). */
+int ekpnp_destroy(ekpnp_ctx* ctx);
+
+/* Message of the last failing call on this context (or of the last failing
+ * ekpnp_create* when ctx == NULL). Never NULL. */
+const char* ekpnp_last_error(const ekpnp_ctx* ctx);
+
+/* Use the caller's HIP stream (a hipStream_t passed as void*) for all device
+ * work of this context instead of the context's own stream. */
+int ekpnp_set_stream(ekpnp_ctx* ctx, void* hip_stream);
+int ekpnp_synchronize(ekpnp_ctx* ctx);
+
+/* Back macroscopic field `field_id` by caller-owned device memory (nz_local*ny*nx
+ * doubles, reference layout) instead of the context's own allocation: this is how
+ * main.cu's rho_gpu ... T_gpu (main.cu:96-106) stay the arrays it copies out. */
+int ekpnp_bind_field(ekpnp_ctx* ctx, int field_id, double* device_ptr);
+int ekpnp_field_device_ptr(ekpnp_ctx* ctx, int field_id, double** device_ptr);
+
+/* Host <-> device transfer of one macroscopic field of this context's planes
+ * (nz_local*ny*nx doubles), replacing the cudaMemcpy calls of main.cu:211-213 and
+ * LBM.cu:2511-2521 / 2645-2657. */
+int ekpnp_set_field(ekpnp_ctx* ctx, int field_id, const double* host);
+int ekpnp_get_field(ekpnp_ctx* ctx, int field_id, double* host);
+
+/* void initialization(r,c,cn,fi,u,v,w,ex,ey,ez,temp)  — LBM.h:159, LBM.cu:68-109:
+ * uniform fields + pb_iterations Poisson-Boltzmann sweeps, all on the device. */
+int ekpnp_initialization(ekpnp_ctx* ctx);
+
+/* void init_equilibrium(f0,f1,h0,h1,hn0,hn1,temp0,temp1,r,c,cn,u,v,w,ex,ey,ez,temp)
+ * — LBM.h:162-163, LBM.cu:150-160: populations <- equilibrium of the fields. */
+int ekpnp_init_equilibrium(ekpnp_ctx* ctx);
+
+/* void stream_collide_save(f0,f1,f2,h0,...,Temp,double t,double* f0bc)
+ * — LBM.h:165-166, LBM.cu:465-481: one collide + wall + stream + ion/thermal wall
+ * sweep; writes the pre-collision moments rho,u,c,cn,T like LBM.cu:807-813. */
+int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t);
+
+/* void fast_Poisson(charge, chargen, kx, ky, kz, plan) — LBM.h:176, poisson.cu:75-103,
+ * including its efield() tail (poisson.cu:28-69): phi, Ex, Ey, Ez from c, cn. */
+int ekpnp_fast_poisson(ekpnp_ctx* ctx);
+
+/* The time loop body of main.cu:189-200, n times:
+ * stream_collide_save; fast_Poisson; t += dt. */
+int ekpnp_step(ekpnp_ctx* ctx, int nsteps);
+int ekpnp_get_time(ekpnp_ctx* ctx, double* t);
+int ekpnp_set_time(ekpnp_ctx* ctx, double t);
+
+/* Lattice geometry of this context: global nz, first owned plane, owned planes. */
+int ekpnp_local_extent(ekpnp_ctx* ctx, int* z0, int* nz_local);
+
+/* ---- measurement hooks (bench.py; no reference counterpart) ------------------ */
+/* When enabled, every launch of the bulk collide/stream kernel is bracketed by
+ * HIP events on the context's stream; the sum is returned by ..._get. */
+int ekpnp_kernel_timing_enable(ekpnp_ctx* ctx, int enable);
+int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* total_ms,
+                            int64_t* nodes_per_launch);
+size_t ekpnp_device_bytes(const ekpnp_ctx* ctx);
+
+/* ---- z-slab halo interface (no reference counterpart) ------- */
+/* The populations a neighbour needs after a collide: the 9 c_z=+1 directions of
+ * the top owned plane go up, the 9 c_z=-1 directions of the bottom plane go down,
+ * for each active lattice; gpu_stream's z wrap (LBM.cu:1972,1975) closes the ring.
+ * which: 0 = send-down, 1 = send-up, 2 = recv-from-below, 3 = recv-from-above.   */
+int ekpnp_halo_buffer(ekpnp_ctx* ctx, int which, double** device_ptr, size_t* n_doubles);
+int ekpnp_halo_pack(ekpnp_ctx* ctx);    /* post-collision boundary planes -> send buffers */
+int ekpnp_halo_unpack(ekpnp_ctx* ctx);  /* recv buffers -> ghost planes                   */
+/* One phi plane each way for Ez (poisson.cu:50-55); same `which` numbering. */
+int ekpnp_phi_halo_buffer(ekpnp_ctx* ctx, int which, double** device_ptr, size_t* n_doubles);
+/* Distributed z-tridiagonal (replaces the z part of the 3-D cuFFT, poisson.cu:86-92):
+ * stage 1 = rhs + 2-D FFT + local solve, leaves 2 interface coefficients per
+ * (kx,ky) mode in the edge buffer; the caller all-gathers the edge buffers of all
+ * ranks (rank-major) into the gathered buffer; stage 2 = reduced solve + correction
+ * + inverse FFT + phi; stage 3 (after the phi halo exchange) = E field. */
+int ekpnp_poisson_stage1(ekpnp_ctx* ctx);
+int ekpnp_poisson_edge_buffer(ekpnp_ctx* ctx, int gathered, double** device_ptr, size_t* n_doubles);
+int ekpnp_poisson_stage2(ekpnp_ctx* ctx);
+int ekpnp_phi_halo_pack(ekpnp_ctx* ctx);
+int ekpnp_poisson_stage3(ekpnp_ctx* ctx);
+/* Split form of ekpnp_stream_collide_save for halo/compute overlap:
+ * boundary planes first (then pack + start the exchange), interior afterwards. */
+int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx);
+int ekpnp_collide_interior_planes(ekpnp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EKPNP_H */

@@ -1,0 +1,706 @@
+/*
+ * ekpnp_oracle.c — CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP path: a plain-C, table-driven
+ * restatement of gyf135/EK-PNP-3D's per-step algorithm (LBM.cu / poisson.cu),
+ * structured like the reference (separate collide / boundary / stream / bc_charge
+ * passes over f1 -> f2 -> f1, 3-D complex DFT of the odd extension for Poisson).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it;
+ * the product library never links, imports or calls anything in oracle/.
+ *
+ * Pinning: the reference ships no tests, fixtures or golden vectors,
+ * so this restatement is pinned against tests/golden/ref_*.npz, which were produced
+ * by the reference's own kernels built for gfx950 (oracle/build_ref.sh) and run on an
+ * MI355X (see DESIGN.md "Oracle").  Two reference ambiguities are canonicalised here
+ * exactly as SURVEY.md §8(c) prescribes:
+ *   (1) the z==0 thread of gpu_collide_save reads node z=1's rest populations
+ *       (LBM.cu:664-667) which the z=1 thread overwrites in place (LBM.cu:1711-1714):
+ *       the oracle always reads the PRE-collision values;
+ *   (2) the DC mode of the Poisson solve is divided by mu=1 in the reference
+ *       (poisson.cu:177) and carries FFT-library rounding residue: dc_mode==0 forces
+ *       it to exactly 0 (canonical), dc_mode==1 keeps the reference's division.
+ *
+ * Every function cites the reference lines it follows.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/ekpnp.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define Q 27
+
+/* D3Q27 velocity set, recovered from the stream offsets of gpu_stream
+ * (LBM.cu:1983-2008): f1[d](x) = f2[d](x - c_d).  Opposite of odd d is d+1. */
+static const int EX[Q] = {0, 1, -1, 0, 0, 0, 0, 1, -1, 1, -1, 0, 0, 1, -1, 1, -1, 0, 0, 1, -1, 1, -1, 1, -1, -1, 1};
+static const int EY[Q] = {0, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, -1, 1, 0, 0, 1, -1, 1, -1, 1, -1, -1, 1, 1, -1};
+static const int EZ[Q] = {0, 0, 0, 0, 0, 1, -1, 0, 0, 1, -1, 1, -1, 0, 0, -1, 1, -1, 1, 1, -1, -1, 1, 1, -1, 1, -1};
+
+/* Order in which the reference adds the components of c_i.u for the corner
+ * directions 19..26 (LBM.cu:447-462, 1088-1103): entries are +-(axis+1). */
+static const int CORNER_ORDER[8][3] = {
+    {+1, +2, +3}, /* 19: tux + tuy + tuz  */
+    {-1, -2, -3}, /* 20: -tux - tuy - tuz */
+    {+1, +2, -3}, /* 21: tux + tuy - tuz  */
+    {+3, -1, -2}, /* 22: tuz - tux - tuy  */
+    {+1, +3, -2}, /* 23: tux + tuz - tuy  */
+    {+2, -1, -3}, /* 24: tuy - tux - tuz  */
+    {+2, +3, -1}, /* 25: tuy + tuz - tux  */
+    {+1, -2, -3}, /* 26: tux - tuy - tuz  */
+};
+
+/* Momentum sums exactly as written at LBM.cu:639-644. */
+static const int MX_P[9] = {1, 7, 9, 13, 15, 19, 21, 23, 26}, MX_M[9] = {2, 8, 10, 14, 16, 20, 22, 24, 25};
+static const int MY_P[9] = {3, 7, 11, 14, 17, 19, 21, 24, 25}, MY_M[9] = {4, 8, 12, 13, 18, 20, 22, 23, 26};
+static const int MZ_P[9] = {5, 9, 11, 16, 18, 19, 22, 23, 25}, MZ_M[9] = {6, 10, 12, 15, 17, 20, 21, 24, 26};
+
+typedef struct {
+  double re, im;
+} cplx;
+
+typedef struct oracle_state {
+  ekpnp_params p;
+  size_t n;  /* nodes */
+  int ne;    /* NE = 2*(NZ-1), LBM.h:37 */
+  int dc_mode;
+  /* populations, reference layout: X0[NZ][NY][NX], X1/X2[26][NZ][NY][NX] (LBM.cu:17-30) */
+  double *x0[4], *x1[4], *x2[4];
+  double* f0bc; /* [2][NY][NX], main.cu:78 */
+  double* fld[EKPNP_NFIELDS];
+  double* phi_old;
+  cplx *ext_a, *ext_b; /* odd-extension work arrays, [NE][NY][NX] */
+  double *kx, *ky, *kz;
+  double w[Q];
+} oracle_state;
+
+static inline size_t sidx(const oracle_state* s, int x, int y, int z) {
+  return (size_t)s->p.nx * ((size_t)s->p.ny * z + y) + x; /* LBM.cu:22-25 */
+}
+static inline size_t nidx(const oracle_state* s, int x, int y, int z, int d) {
+  return (size_t)s->p.nx * ((size_t)s->p.ny * ((size_t)s->p.nz * (d - 1) + z) + y) + x; /* LBM.cu:27-30 */
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* parameters                                                                                 */
+
+/* Defaults of LBM.h:29-118, written with the reference's own literal expressions so that the
+ * derived constants carry the same bits. */
+int oracle_default_params(ekpnp_params* p, int nx, int ny, int nz) {
+  memset(p, 0, sizeof(*p));
+  p->nx = nx; p->ny = ny; p->nz = nz;
+  p->n_lattices = 4;
+  p->pb_iterations = 501;
+  p->dx = 1.0e-6 / 100.0; p->dy = 1.0e-6 / 100.0; p->dz = 1.0e-6 / 100.0;
+  p->Lx = nx * p->dx; p->Ly = ny * p->dy; p->Lz = (nz - 1) * p->dz;
+  p->CFL = 0.01;
+  p->dt = 0.01 * 1.0e-6 / 100.0;
+  p->cs_square = 1.0 / 3.0 / (0.01 * 0.01);
+  p->rho0 = 1000.0;
+  p->chargeinf = 0.01;
+  p->voltage = -5.2574e-3; p->voltage2 = -5.2574e-3;
+  p->Ext = 1.0e4;
+  p->eps = 6.95e-10;
+  p->diffu = 1.0e-8; p->diffun = 1.0e-8;
+  p->nu = 0.889e-6;
+  p->K = 4.245e-7; p->Kn = -4.245e-7;
+  p->D = 0.889e-6; p->Ra = 1; p->TH = 1;
+  p->uw = 0.0; p->exf = 0.0;
+  p->kB = 1.38e-23; p->electron = 1.6e-19; p->roomT = 273.0;
+  p->convertCtoCharge = 9.64e4;
+  p->PB_omega = 0.05;
+  p->V = 1.0 / 12.0; p->VC = 1.0e-6; p->VCn = 1.0e-6; p->VT = 1.0 / 12.0;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* allocation (main.cu:78-152)                                                                */
+
+oracle_state* oracle_create(const ekpnp_params* p, int dc_mode) {
+  oracle_state* s = (oracle_state*)calloc(1, sizeof(*s));
+  s->p = *p;
+  s->n = (size_t)p->nx * p->ny * p->nz;
+  s->ne = 2 * (p->nz - 1);
+  s->dc_mode = dc_mode;
+  for (int l = 0; l < 4; ++l) {
+    s->x0[l] = (double*)calloc(s->n, sizeof(double));
+    s->x1[l] = (double*)calloc(s->n * 26, sizeof(double));
+    s->x2[l] = (double*)calloc(s->n * 26, sizeof(double));
+  }
+  s->f0bc = (double*)calloc((size_t)2 * p->nx * p->ny, sizeof(double));
+  for (int i = 0; i < EKPNP_NFIELDS; ++i) s->fld[i] = (double*)calloc(s->n, sizeof(double));
+  s->phi_old = (double*)calloc(s->n, sizeof(double));
+  size_t next = (size_t)p->nx * p->ny * s->ne;
+  s->ext_a = (cplx*)calloc(next, sizeof(cplx));
+  s->ext_b = (cplx*)calloc(next, sizeof(cplx));
+  s->kx = (double*)calloc(p->nx, sizeof(double));
+  s->ky = (double*)calloc(p->ny, sizeof(double));
+  s->kz = (double*)calloc(s->ne, sizeof(double));
+  /* wavenumbers, main.cu:119-144 */
+  for (int i = 0; i <= p->nx / 2; i++) s->kx[i] = (double)i * 2.0 * M_PI / p->Lx;
+  for (int i = p->nx / 2 + 1; i < p->nx; i++) s->kx[i] = ((double)i - p->nx) * 2.0 * M_PI / p->Lx;
+  for (int i = 0; i <= p->ny / 2; i++) s->ky[i] = (double)i * 2.0 * M_PI / p->Ly;
+  for (int i = p->ny / 2 + 1; i < p->ny; i++) s->ky[i] = ((double)i - p->ny) * 2.0 * M_PI / p->Ly;
+  for (int i = 0; i <= s->ne / 2; i++) s->kz[i] = (double)i * 2.0 * M_PI / (s->ne * p->dz);
+  for (int i = s->ne / 2 + 1; i < s->ne; i++) s->kz[i] = ((double)i - s->ne) * 2.0 * M_PI / (s->ne * p->dz);
+  /* weights, LBM.h:109-112 */
+  s->w[0] = 8.0 / 27.0;
+  for (int d = 1; d <= 6; ++d) s->w[d] = 2.0 / 27.0;
+  for (int d = 7; d <= 18; ++d) s->w[d] = 1.0 / 54.0;
+  for (int d = 19; d <= 26; ++d) s->w[d] = 1.0 / 216.0;
+  return s;
+}
+
+void oracle_destroy(oracle_state* s) {
+  if (!s) return;
+  for (int l = 0; l < 4; ++l) { free(s->x0[l]); free(s->x1[l]); free(s->x2[l]); }
+  free(s->f0bc);
+  for (int i = 0; i < EKPNP_NFIELDS; ++i) free(s->fld[i]);
+  free(s->phi_old); free(s->ext_a); free(s->ext_b); free(s->kx); free(s->ky); free(s->kz);
+  free(s);
+}
+
+double* oracle_field(oracle_state* s, int id) { return s->fld[id]; }
+/* which: 0 -> X0, 1 -> X1 (current), 2 -> X2 (post-collision) of lattice l (0 f, 1 h, 2 hn, 3 temp) */
+double* oracle_population(oracle_state* s, int l, int which) {
+  return which == 0 ? s->x0[l] : which == 1 ? s->x1[l] : s->x2[l];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* equilibrium helper shared by gpu_init_equilibrium (LBM.cu:207-462) and                     */
+/* gpu_collide_save (LBM.cu:830-1103): eq_i = w_i m [omusq + t (1 + t/2)], t = c_i.v/cs^2      */
+
+static void equilibrium(const oracle_state* s, double m, double vx, double vy, double vz, double* eq) {
+  const double cs2 = s->p.cs_square, CFL = s->p.CFL;
+  const double omusq = 1.0 - 0.5 * (vx * vx + vy * vy + vz * vz) / cs2;
+  const double t[3] = {vx / cs2 / CFL, vy / cs2 / CFL, vz / cs2 / CFL};
+  eq[0] = (s->w[0] * m) * omusq;
+  for (int d = 1; d < Q; ++d) {
+    double ci;
+    if (d <= 6) {
+      ci = EX[d] * t[0] + EY[d] * t[1] + EZ[d] * t[2]; /* single non-zero term: exact */
+    } else if (d <= 18) {
+      /* two terms: a+b is commutative in IEEE arithmetic, (-a)-b == -(a+b) */
+      double a = 0.0, b = 0.0;
+      int k = 0;
+      const int e[3] = {EX[d], EY[d], EZ[d]};
+      for (int ax = 0; ax < 3; ++ax)
+        if (e[ax]) { if (k++ == 0) a = e[ax] * t[ax]; else b = e[ax] * t[ax]; }
+      ci = a + b;
+    } else {
+      const int* o = CORNER_ORDER[d - 19];
+      double a = (o[0] > 0 ? t[o[0] - 1] : -t[-o[0] - 1]);
+      a = a + (o[1] > 0 ? t[o[1] - 1] : -t[-o[1] - 1]);
+      a = a + (o[2] > 0 ? t[o[2] - 1] : -t[-o[2] - 1]);
+      ci = a;
+    }
+    eq[d] = (s->w[d] * m) * (omusq + ci * (1.0 + 0.5 * ci));
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* gpu_initialization, LBM.cu:111-128                                                         */
+
+void oracle_gpu_initialization(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+  for (int z = 0; z < p->nz; ++z)
+    for (int y = 0; y < p->ny; ++y)
+      for (int x = 0; x < p->nx; ++x) {
+        size_t i = sidx(s, x, y, z);
+        s->fld[EKPNP_RHO][i] = p->rho0;
+        s->fld[EKPNP_C][i] = 0.0;
+        s->fld[EKPNP_CN][i] = 0.0;
+        s->fld[EKPNP_PHI][i] = p->voltage;
+        s->fld[EKPNP_UX][i] = 0.0; s->fld[EKPNP_UY][i] = 0.0; s->fld[EKPNP_UZ][i] = 0.0;
+        s->fld[EKPNP_EX][i] = 0.0; s->fld[EKPNP_EY][i] = 0.0; s->fld[EKPNP_EZ][i] = 0.0;
+        s->fld[EKPNP_T][i] = p->TH * (p->Lz - p->dz * z) / p->Lz;
+      }
+}
+
+/* gpu_PBE, LBM.cu:139-146 */
+void oracle_gpu_PBE(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+#pragma omp parallel for
+  for (long i = 0; i < (long)s->n; ++i) {
+    double fi = s->fld[EKPNP_PHI][i];
+    s->fld[EKPNP_C][i] = p->chargeinf * exp(-p->electron * fi / p->kB / p->roomT);
+    s->fld[EKPNP_CN][i] = p->chargeinf * exp(p->electron * fi / p->kB / p->roomT);
+  }
+}
+
+/* gpu_PBE_phi, LBM.cu:131-137 */
+void oracle_gpu_PBE_phi(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+#pragma omp parallel for
+  for (long i = 0; i < (long)s->n; ++i)
+    s->fld[EKPNP_PHI][i] = p->PB_omega * s->fld[EKPNP_PHI][i] + (1.0 - p->PB_omega) * s->phi_old[i];
+}
+
+void oracle_fast_poisson(oracle_state* s);
+
+/* initialization, LBM.cu:68-109 */
+void oracle_initialization(oracle_state* s) {
+  oracle_gpu_initialization(s);
+  memcpy(s->phi_old, s->fld[EKPNP_PHI], s->n * sizeof(double)); /* LBM.cu:82-86 */
+  for (int i = 0; i < s->p.pb_iterations; ++i) {                 /* LBM.cu:89: i = 0..500 */
+    oracle_gpu_PBE(s);
+    oracle_fast_poisson(s);
+    oracle_gpu_PBE_phi(s);
+    memcpy(s->phi_old, s->fld[EKPNP_PHI], s->n * sizeof(double)); /* LBM.cu:101-104 */
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* gpu_init_equilibrium, LBM.cu:162-463                                                       */
+
+void oracle_init_equilibrium(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+#pragma omp parallel for
+  for (int z = 0; z < p->nz; ++z)
+    for (int y = 0; y < p->ny; ++y)
+      for (int x = 0; x < p->nx; ++x) {
+        size_t i = sidx(s, x, y, z);
+        double rho = s->fld[EKPNP_RHO][i], ux = s->fld[EKPNP_UX][i], uy = s->fld[EKPNP_UY][i], uz = s->fld[EKPNP_UZ][i];
+        double c = s->fld[EKPNP_C][i], cn = s->fld[EKPNP_CN][i], T = s->fld[EKPNP_T][i];
+        double Ex = s->fld[EKPNP_EX][i], Ey = s->fld[EKPNP_EY][i], Ez = s->fld[EKPNP_EZ][i];
+        double eq[4][Q];
+        equilibrium(s, rho, ux, uy, uz, eq[0]);
+        equilibrium(s, c, ux + p->K * Ex, uy + p->K * Ey, uz + p->K * Ez, eq[1]);
+        equilibrium(s, cn, ux + p->Kn * Ex, uy + p->Kn * Ey, uz + p->Kn * Ez, eq[2]);
+        equilibrium(s, T, ux, uy, uz, eq[3]);
+        for (int l = 0; l < 4; ++l) {
+          s->x0[l][i] = eq[l][0];
+          for (int d = 1; d < Q; ++d) s->x1[l][nidx(s, x, y, z, d)] = eq[l][d];
+        }
+      }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* gpu_collide_save, LBM.cu:483-1846                                                          */
+
+static void load_node(const oracle_state* s, int l, int x, int y, int z, const double* x0, double* ft) {
+  ft[0] = x0[sidx(s, x, y, z)];
+  for (int d = 1; d < Q; ++d) ft[d] = s->x1[l][nidx(s, x, y, z, d)];
+}
+
+static double sum27(const double* f) { /* LBM.cu:621-630: index order 0..26 */
+  double a = f[0];
+  for (int d = 1; d < Q; ++d) a = a + f[d];
+  return a;
+}
+
+static double sum9(const double* f, const int* idx) {
+  double a = f[idx[0]];
+  for (int k = 1; k < 9; ++k) a = a + f[idx[k]];
+  return a;
+}
+
+/* TRT relaxation of one lattice, LBM.cu:1148-1658 and 1700-1845.  src may be NULL. */
+static void trt(const double* ft, const double* fe, const double* src, double wp, double wm, double dt, double* out) {
+  /* rest population: fp0 = ft0, fm0 = 0, fep0 = fe0, fem0 = 0 */
+  out[0] = ft[0] - (wp * (ft[0] - fe[0]) + wm * (0.0 - 0.0));
+  if (src) out[0] = out[0] + dt * src[0];
+  for (int d = 1; d < Q; d += 2) {
+    double fp = 0.5 * (ft[d] + ft[d + 1]), fm = 0.5 * (ft[d] - ft[d + 1]);
+    double ep = 0.5 * (fe[d] + fe[d + 1]), em = 0.5 * (fe[d] - fe[d + 1]);
+    double a = ft[d] - (wp * (fp - ep) + wm * (fm - em));
+    double b = ft[d + 1] - (wp * (fp - ep) + wm * ((-fm) - (-em)));
+    if (src) { a = a + dt * src[d]; b = b + dt * src[d + 1]; }
+    out[d] = a; out[d + 1] = b;
+  }
+}
+
+void oracle_collide_save(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+  const double cs2 = p->cs_square, dt = p->dt, CFL = p->CFL;
+  /* LBM.cu:488-495 */
+  const double omega_plus = 1.0 / (p->nu / cs2 / dt + 1.0 / 2.0) / dt;
+  const double omega_minus = 1.0 / (p->V / (p->nu / cs2 / dt) + 1.0 / 2.0) / dt;
+  const double omega_c_minus = 1.0 / (p->diffu / cs2 / dt + 1.0 / 2.0) / dt;
+  const double omega_c_plus = 1.0 / (p->VC / (p->diffu / cs2 / dt) + 1.0 / 2.0) / dt;
+  const double omega_cn_minus = 1.0 / (p->diffun / cs2 / dt + 1.0 / 2.0) / dt;
+  const double omega_cn_plus = 1.0 / (p->VCn / (p->diffun / cs2 / dt) + 1.0 / 2.0) / dt;
+  const double omega_T_minus = 1.0 / (p->D / cs2 / dt + 1.0 / 2.0) / dt;
+  const double omega_T_plus = 1.0 / (p->VT / (p->D / cs2 / dt) + 1.0 / 2.0) / dt;
+  const double F = p->convertCtoCharge;
+  const int NX = p->nx, NY = p->ny, NZ = p->nz;
+  const size_t plane = (size_t)NX * NY;
+
+  /* canonicalisation (1): keep plane z=1's pre-collision rest populations for the z==0 override */
+  double* rest1[4];
+  for (int l = 0; l < 4; ++l) {
+    rest1[l] = (double*)malloc(plane * sizeof(double));
+    memcpy(rest1[l], s->x0[l] + plane, plane * sizeof(double));
+  }
+
+#pragma omp parallel for
+  for (int z = 0; z < NZ; ++z)
+    for (int y = 0; y < NY; ++y)
+      for (int x = 0; x < NX; ++x) {
+        const size_t i = sidx(s, x, y, z);
+        /* LBM.cu:502-504 */
+        if (z == 0) s->f0bc[sidx(s, x, y, 0)] = s->x0[0][i];
+        if (z == NZ - 1) s->f0bc[sidx(s, x, y, 1)] = s->x0[0][i];
+
+        double ft[4][Q];
+        for (int l = 0; l < 4; ++l) load_node(s, l, x, y, z, s->x0[l], ft[l]);
+        double rho = sum27(ft[0]);
+        double rhoinv = 1.0 / rho;
+        double charge = sum27(ft[1]), chargen = sum27(ft[2]), temp = sum27(ft[3]);
+
+        double Ex = s->fld[EKPNP_EX][i], Ey = s->fld[EKPNP_EY][i], Ez = s->fld[EKPNP_EZ][i];
+        /* LBM.cu:635-637 */
+        double forcex = F * (charge - chargen) * (Ex + p->Ext) + p->exf;
+        double forcey = F * (charge - chargen) * Ey;
+        double forcez = F * (charge - chargen) * Ez + p->rho0 * temp * p->Ra * p->nu * p->D;
+        /* LBM.cu:639-644 */
+        double ux = rhoinv * ((sum9(ft[0], MX_P) - (sum9(ft[0], MX_M))) / CFL + forcex * dt * 0.5);
+        double uy = rhoinv * ((sum9(ft[0], MY_P) - (sum9(ft[0], MY_M))) / CFL + forcey * dt * 0.5);
+        double uz = rhoinv * ((sum9(ft[0], MZ_P) - (sum9(ft[0], MZ_M))) / CFL + forcez * dt * 0.5);
+
+        if (z == 0) { /* LBM.cu:663-801; perturb is always 0 (LBM.h:18, LBM.cu:1856) */
+          double fm_[4][Q];
+          for (int l = 0; l < 4; ++l) {
+            fm_[l][0] = rest1[l][sidx(s, x, y, 0)]; /* node (x,y,1), pre-collision */
+            for (int d = 1; d < Q; ++d) fm_[l][d] = s->x1[l][nidx(s, x, y, 1, d)];
+          }
+          double rhoinvm = 1.0 / rho; /* sic: LBM.cu:780 uses rho of node z=0 */
+          double chargem = sum27(fm_[1]), chargenm = sum27(fm_[2]), tempm = sum27(fm_[3]);
+          size_t i1 = sidx(s, x, y, 1);
+          double Exm = s->fld[EKPNP_EX][i1], Eym = s->fld[EKPNP_EY][i1], Ezm = s->fld[EKPNP_EZ][i1];
+          double forcexm = F * (chargem - chargenm) * (Exm + p->Ext) + p->exf;
+          double forceym = F * (chargem - chargenm) * Eym;
+          double forcezm = F * (chargem - chargenm) * Ezm + p->rho0 * tempm * p->Ra * p->nu * p->D;
+          ux = -rhoinvm * ((sum9(fm_[0], MX_P) - (sum9(fm_[0], MX_M))) / CFL + forcexm * dt * 0.5);
+          uy = -rhoinvm * ((sum9(fm_[0], MY_P) - (sum9(fm_[0], MY_M))) / CFL + forceym * dt * 0.5);
+          uz = -rhoinvm * ((sum9(fm_[0], MZ_P) - (sum9(fm_[0], MZ_M))) / CFL + forcezm * dt * 0.5);
+        }
+
+        /* LBM.cu:807-813 */
+        s->fld[EKPNP_RHO][i] = rho;
+        s->fld[EKPNP_UX][i] = ux; s->fld[EKPNP_UY][i] = uy; s->fld[EKPNP_UZ][i] = uz;
+        s->fld[EKPNP_C][i] = charge; s->fld[EKPNP_CN][i] = chargen;
+        s->fld[EKPNP_T][i] = temp;
+
+        /* equilibria, LBM.cu:830-1103 */
+        double fe[4][Q];
+        equilibrium(s, rho, ux, uy, uz, fe[0]);
+        equilibrium(s, charge, ux + p->K * Ex, uy + p->K * Ey, uz + p->K * Ez, fe[1]);
+        equilibrium(s, chargen, ux + p->Kn * Ex, uy + p->Kn * Ey, uz + p->Kn * Ez, fe[2]);
+        equilibrium(s, temp, ux, uy, uz, fe[3]);
+
+        /* Guo force populations, LBM.cu:1107-1145 */
+        double fpop[Q];
+        {
+          const double cflinv = 1.0 / CFL;
+          const double cflinv2 = cflinv * cflinv / cs2;
+          const double u[3] = {ux, uy, uz}, f[3] = {forcex, forcey, forcez};
+          fpop[0] = -(s->w[0] / cs2) * (ux * forcex + uy * forcey + uz * forcez);
+          for (int d = 1; d < Q; ++d) {
+            const int e[3] = {EX[d], EY[d], EZ[d]};
+            const double coe = s->w[d] / cs2;
+            /* c_i.u written as the signed sum in x,y,z order (e.g. "ux - uy + uz") */
+            double eu = 0.0;
+            int first = 1;
+            for (int ax = 0; ax < 3; ++ax)
+              if (e[ax]) { if (first) { eu = e[ax] * u[ax]; first = 0; } else eu = eu + e[ax] * u[ax]; }
+            int nmove = (e[0] != 0) + (e[1] != 0) + (e[2] != 0);
+            double acc = 0.0;
+            if (nmove == 1) {
+              /* "-uy*forcey - uz*forcez + ((+-cflinv - ux) + (cflinv2*ux))*forcex" */
+              int a = e[0] ? 0 : e[1] ? 1 : 2;
+              int b = (a == 0) ? 1 : 0, c = (a == 2) ? 1 : 2;
+              acc = -u[b] * f[b] - u[c] * f[c] + ((e[a] * cflinv - u[a]) + (cflinv2 * u[a])) * f[a];
+            } else {
+              /* moving axes first in x,y,z order, then "- u_b*force_b" of the still axis */
+              first = 1;
+              for (int ax = 0; ax < 3; ++ax)
+                if (e[ax]) {
+                  double term = ((e[ax] * cflinv - u[ax]) + (e[ax] * eu) * cflinv2) * f[ax];
+                  if (first) { acc = term; first = 0; } else acc = acc + term;
+                }
+              for (int ax = 0; ax < 3; ++ax)
+                if (!e[ax]) acc = acc - u[ax] * f[ax];
+            }
+            fpop[d] = coe * acc;
+          }
+        }
+        /* source, LBM.cu:1603-1689 */
+        double source[Q];
+        {
+          const double sp = 1.0 - 0.5 * dt * omega_plus, sm = 1.0 - 0.5 * dt * omega_minus;
+          source[0] = sp * fpop[0];
+          for (int d = 1; d < Q; d += 2) {
+            double fp = 0.5 * (fpop[d] + fpop[d + 1]), fm = 0.5 * (fpop[d] - fpop[d + 1]);
+            source[d] = sp * fp + sm * fm;
+            source[d + 1] = sp * fp + sm * (-fm);
+          }
+        }
+        /* TRT, LBM.cu:1700-1845 */
+        double out[4][Q];
+        trt(ft[0], fe[0], source, omega_plus * dt, omega_minus * dt, dt, out[0]);
+        trt(ft[1], fe[1], NULL, omega_c_plus * dt, omega_c_minus * dt, dt, out[1]);
+        trt(ft[2], fe[2], NULL, omega_cn_plus * dt, omega_cn_minus * dt, dt, out[2]);
+        trt(ft[3], fe[3], NULL, omega_T_plus * dt, omega_T_minus * dt, dt, out[3]);
+        for (int l = 0; l < 4; ++l) {
+          s->x0[l][i] = out[l][0];
+          for (int d = 1; d < Q; ++d) s->x2[l][nidx(s, x, y, z, d)] = out[l][d];
+        }
+      }
+  for (int l = 0; l < 4; ++l) free(rest1[l]);
+}
+
+/* gpu_boundary, LBM.cu:1848-1961 */
+void oracle_boundary(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+  const int NZ = p->nz;
+  for (int y = 0; y < p->ny; ++y)
+    for (int x = 0; x < p->nx; ++x) {
+      /* lower plate, LBM.cu:1859-1889 */
+      s->x0[0][sidx(s, x, y, 0)] = s->f0bc[sidx(s, x, y, 0)];
+      for (int d = 1; d < Q; d += 2) {
+        s->x2[0][nidx(s, x, y, 0, d)] = s->x1[0][nidx(s, x, y, 0, d + 1)];
+        s->x2[0][nidx(s, x, y, 0, d + 1)] = s->x1[0][nidx(s, x, y, 0, d)];
+      }
+      /* upper plate, LBM.cu:1896-1927: +-2 rho0 uw w /(cs^2 CFL) on the x-moving directions,
+       * and (sic) "+ multis" on direction 3 only (LBM.cu:1904-1905). */
+      s->x0[0][sidx(s, x, y, NZ - 1)] = s->f0bc[sidx(s, x, y, 1)];
+      for (int d = 1; d < Q; ++d) {
+        int od = (d & 1) ? d + 1 : d - 1;
+        double multi = 2.0 * p->rho0 * p->uw / p->cs_square * s->w[d] / p->CFL;
+        double v = s->x1[0][nidx(s, x, y, NZ - 1, od)];
+        if (EX[d] > 0 || d == 3) v = v + multi;
+        else if (EX[d] < 0) v = v - multi;
+        s->x2[0][nidx(s, x, y, NZ - 1, d)] = v;
+      }
+    }
+}
+
+/* gpu_stream, LBM.cu:1963-2093: X1[d](x) = X2[d](x - c_d), periodic in x, y AND z */
+void oracle_stream(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+  const int NX = p->nx, NY = p->ny, NZ = p->nz;
+#pragma omp parallel for
+  for (int z = 0; z < NZ; ++z)
+    for (int y = 0; y < NY; ++y)
+      for (int x = 0; x < NX; ++x)
+        for (int d = 1; d < Q; ++d) {
+          int xs = (x - EX[d] + NX) % NX, ys = (y - EY[d] + NY) % NY, zs = (z - EZ[d] + NZ) % NZ;
+          size_t dst = nidx(s, x, y, z, d), src = nidx(s, xs, ys, zs, d);
+          for (int l = 0; l < 4; ++l) s->x1[l][dst] = s->x2[l][src];
+        }
+}
+
+/* gpu_bc_charge, LBM.cu:2095-2416 */
+void oracle_bc_charge(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+  const int NZ = p->nz;
+  for (int wall = 0; wall < 2; ++wall) {
+    int z = wall ? NZ - 1 : 0;
+    double TH = wall ? 0.0 : p->TH; /* LBM.cu:2226-2229 vs 2357-2412 */
+    for (int y = 0; y < p->ny; ++y)
+      for (int x = 0; x < p->nx; ++x) {
+        for (int d = 1; d < Q; ++d) {
+          int od = (d & 1) ? d + 1 : d - 1;
+          /* ions: local swap of the post-collision populations, LBM.cu:2104-2217 */
+          s->x1[1][nidx(s, x, y, z, d)] = s->x2[1][nidx(s, x, y, z, od)];
+          s->x1[2][nidx(s, x, y, z, d)] = s->x2[2][nidx(s, x, y, z, od)];
+          /* temperature: anti-bounce-back, LBM.cu:2321-2349 / 2384-2412 */
+          double v = -s->x2[3][nidx(s, x, y, z, od)];
+          s->x1[3][nidx(s, x, y, z, d)] = wall ? v : v + 2.0 * TH * s->w[d];
+        }
+        size_t i = sidx(s, x, y, z);
+        s->x0[3][i] = wall ? -s->x0[3][i] : -s->x0[3][i] + 2.0 * TH * s->w[0];
+      }
+  }
+}
+
+/* stream_collide_save, LBM.cu:465-481 */
+void oracle_stream_collide_save(oracle_state* s) {
+  oracle_collide_save(s);
+  oracle_boundary(s);
+  oracle_stream(s);
+  oracle_bc_charge(s);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* complex DFT of arbitrary length (stand-in for cuFFT Z2Z, main.cu:112, poisson.cu:86,92):   */
+/* recursive mixed radix, exact unnormalised DFT definition, sign = -1 forward, +1 inverse.   */
+
+typedef struct { int n; cplx* tw; cplx* scratch; } fftplan;
+
+static void fft_rec(const fftplan* pl, int n, const cplx* in, int istride, cplx* out, cplx* tmp) {
+  if (n == 1) { out[0] = in[0]; return; }
+  int pfac = n;
+  for (int f = 2; f * f <= n; ++f) if (n % f == 0) { pfac = f; break; }
+  int m = n / pfac;
+  /* sub-transforms of the pfac decimated sequences into tmp (then combine into out) */
+  for (int r = 0; r < pfac; ++r) fft_rec(pl, m, in + (size_t)r * istride, istride * pfac, tmp + (size_t)r * m, out + (size_t)r * m);
+  int tstep = pl->n / n;
+  for (int k = 0; k < m; ++k)
+    for (int q = 0; q < pfac; ++q) {
+      int kk = k + q * m;
+      double re = 0.0, im = 0.0;
+      for (int r = 0; r < pfac; ++r) {
+        cplx w = pl->tw[((size_t)r * kk % n) * tstep];
+        cplx v = tmp[(size_t)r * m + k];
+        re += w.re * v.re - w.im * v.im;
+        im += w.re * v.im + w.im * v.re;
+      }
+      out[kk].re = re; out[kk].im = im;
+    }
+}
+
+static fftplan make_plan(int n, int sign) {
+  fftplan pl;
+  pl.n = n;
+  pl.tw = (cplx*)malloc(sizeof(cplx) * n);
+  pl.scratch = NULL;
+  for (int k = 0; k < n; ++k) {
+    double a = sign * 2.0 * M_PI * (double)k / (double)n;
+    pl.tw[k].re = cos(a); pl.tw[k].im = sin(a);
+  }
+  return pl;
+}
+
+/* in-place 3-D transform of a[nz][ny][nx] */
+static void fft3d(cplx* a, int nx, int ny, int nz, int sign) {
+  fftplan px = make_plan(nx, sign), py = make_plan(ny, sign), pz = make_plan(nz, sign);
+  int nmax = nx > ny ? nx : ny; if (nz > nmax) nmax = nz;
+#pragma omp parallel
+  {
+    cplx* line = (cplx*)malloc(sizeof(cplx) * nmax);
+    cplx* out = (cplx*)malloc(sizeof(cplx) * nmax);
+    cplx* tmp = (cplx*)malloc(sizeof(cplx) * nmax);
+#pragma omp for
+    for (long r = 0; r < (long)ny * nz; ++r) { /* x lines */
+      cplx* base = a + (size_t)r * nx;
+      fft_rec(&px, nx, base, 1, out, tmp);
+      memcpy(base, out, sizeof(cplx) * nx);
+    }
+#pragma omp for
+    for (long r = 0; r < (long)nx * nz; ++r) { /* y lines */
+      int x = (int)(r % nx), z = (int)(r / nx);
+      cplx* base = a + (size_t)z * ny * nx + x;
+      for (int y = 0; y < ny; ++y) line[y] = base[(size_t)y * nx];
+      fft_rec(&py, ny, line, 1, out, tmp);
+      for (int y = 0; y < ny; ++y) base[(size_t)y * nx] = out[y];
+    }
+#pragma omp for
+    for (long r = 0; r < (long)nx * ny; ++r) { /* z lines */
+      cplx* base = a + r;
+      size_t st = (size_t)nx * ny;
+      for (int z = 0; z < nz; ++z) line[z] = base[(size_t)z * st];
+      fft_rec(&pz, nz, line, 1, out, tmp);
+      for (int z = 0; z < nz; ++z) base[(size_t)z * st] = out[z];
+    }
+    free(line); free(out); free(tmp);
+  }
+  free(px.tw); free(py.tw); free(pz.tw);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fast_Poisson, poisson.cu:75-103                                                            */
+
+/* odd_extension, poisson.cu:114-158 */
+void oracle_odd_extension(oracle_state* s, cplx* ext) {
+  const ekpnp_params* p = &s->p;
+  const int NZ = p->nz, NE = s->ne;
+  const double F = p->convertCtoCharge, eps = p->eps, dz = p->dz;
+  const double* c = s->fld[EKPNP_C];
+  const double* cn = s->fld[EKPNP_CN];
+  for (int z = 0; z < NE; ++z)
+    for (int y = 0; y < p->ny; ++y)
+      for (int x = 0; x < p->nx; ++x) {
+        size_t e = sidx(s, x, y, z);
+        double v;
+        if (z == 0) v = 0.0;
+        else if (z == 1) v = -F * (c[sidx(s, x, y, z)] - cn[sidx(s, x, y, z)]) / eps - p->voltage / dz / dz;
+        else if (z > 1 && z < NZ - 2) v = -F * (c[sidx(s, x, y, z)] - cn[sidx(s, x, y, z)]) / eps;
+        else if (z == NZ - 2) v = -F * (c[sidx(s, x, y, z)] - cn[sidx(s, x, y, z)]) / eps - p->voltage2 / dz / dz;
+        else if (z == NZ - 1) v = 0.0;
+        else if (z == NZ) v = F * (c[sidx(s, x, y, NE - z)] - cn[sidx(s, x, y, NE - z)]) / eps + p->voltage2 / dz / dz;
+        else if (z > NZ && z < NE - 1) v = F * (c[sidx(s, x, y, NE - z)] - cn[sidx(s, x, y, NE - z)]) / eps;
+        else v = F * (c[sidx(s, x, y, 1)] - cn[sidx(s, x, y, 1)]) / eps + p->voltage / dz / dz; /* z == NE-1 */
+        ext[e].re = v; ext[e].im = 0.0;
+      }
+}
+
+/* gpu_derivative, poisson.cu:169-180 */
+void oracle_derivative(oracle_state* s, cplx* a) {
+  const ekpnp_params* p = &s->p;
+  const double dz = p->dz;
+  for (int z = 0; z < s->ne; ++z)
+    for (int y = 0; y < p->ny; ++y)
+      for (int x = 0; x < p->nx; ++x) {
+        double I = s->kx[x], J = s->ky[y], K = s->kz[z];
+        double mu = (4.0 / dz / dz) * (sin(K * dz * 0.5) * sin(K * dz * 0.5)) + I * I + J * J;
+        size_t e = sidx(s, x, y, z);
+        if (y == 0 && x == 0 && z == 0) {
+          if (s->dc_mode == 0) { a[e].re = 0.0; a[e].im = 0.0; continue; } /* canonicalisation (2) */
+          mu = 1.0; /* poisson.cu:177 */
+        }
+        a[e].re = -a[e].re / mu;
+        a[e].im = -a[e].im / mu;
+      }
+}
+
+/* odd_extract, poisson.cu:191-204 */
+void oracle_odd_extract(oracle_state* s, const cplx* a) {
+  const ekpnp_params* p = &s->p;
+  const double size = (double)((unsigned)p->nx * (unsigned)p->ny * (unsigned)s->ne); /* LBM.h:38 */
+  for (int z = 0; z < p->nz; ++z)
+    for (int y = 0; y < p->ny; ++y)
+      for (int x = 0; x < p->nx; ++x) {
+        size_t i = sidx(s, x, y, z);
+        if (z == 0) s->fld[EKPNP_PHI][i] = p->voltage;
+        else if (z == p->nz - 1) s->fld[EKPNP_PHI][i] = p->voltage2;
+        else s->fld[EKPNP_PHI][i] = a[i].re / size;
+      }
+}
+
+/* efield: gpu_efield + gpu_bc, poisson.cu:28-69 */
+void oracle_efield(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+  const int NX = p->nx, NY = p->ny, NZ = p->nz;
+  const double* fi = s->fld[EKPNP_PHI];
+#pragma omp parallel for
+  for (int z = 0; z < NZ; ++z)
+    for (int y = 0; y < NY; ++y)
+      for (int x = 0; x < NX; ++x) {
+        int xp1 = (x + 1) % NX, yp1 = (y + 1) % NY, zp1 = (z + 1) % NZ;
+        int xm1 = (NX + x - 1) % NX, ym1 = (NY + y - 1) % NY, zm1 = (NZ + z - 1) % NZ;
+        size_t i = sidx(s, x, y, z);
+        s->fld[EKPNP_EX][i] = 0.5 * (fi[sidx(s, xm1, y, z)] - fi[sidx(s, xp1, y, z)]) / p->dx;
+        s->fld[EKPNP_EY][i] = 0.5 * (fi[sidx(s, x, ym1, z)] - fi[sidx(s, x, yp1, z)]) / p->dy;
+        s->fld[EKPNP_EZ][i] = 0.5 * (fi[sidx(s, x, y, zm1)] - fi[sidx(s, x, y, zp1)]) / p->dz;
+      }
+  for (int y = 0; y < NY; ++y)
+    for (int x = 0; x < NX; ++x) {
+      s->fld[EKPNP_EZ][sidx(s, x, y, 0)] = s->fld[EKPNP_EZ][sidx(s, x, y, 1)];
+      s->fld[EKPNP_EZ][sidx(s, x, y, NZ - 1)] = s->fld[EKPNP_EZ][sidx(s, x, y, NZ - 2)];
+    }
+}
+
+void oracle_fast_poisson(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+  oracle_odd_extension(s, s->ext_a);
+  fft3d(s->ext_a, p->nx, p->ny, s->ne, -1);
+  oracle_derivative(s, s->ext_a);
+  fft3d(s->ext_a, p->nx, p->ny, s->ne, +1);
+  oracle_odd_extract(s, s->ext_a);
+  oracle_efield(s);
+}
+
+/* main.cu:189-200 */
+void oracle_step(oracle_state* s, int nsteps) {
+  for (int i = 0; i < nsteps; ++i) {
+    oracle_stream_collide_save(s);
+    oracle_fast_poisson(s);
+  }
+}

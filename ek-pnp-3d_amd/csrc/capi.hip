@@ -1,0 +1,503 @@
+// capi.hip — the C ABI of include/ekpnp.h: context, memory, plans, step orchestration.
+// Host-side replacement of main.cu:58-152,189-200,264-290 and of the host wrappers
+// initialization / init_equilibrium / stream_collide_save / fast_Poisson
+// (LBM.cu:68-109,150-160,465-481; poisson.cu:75-103).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ekpnp_internal.h"
+
+using namespace ekpnp;
+
+struct ekpnp_ctx {
+  Ctx c;
+};
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(ctx, call)                                                                       \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      (ctx).err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+      return e_ == hipErrorOutOfMemory ? EKPNP_ERR_NOMEM : EKPNP_ERR_HIP;                       \
+    }                                                                                           \
+  } while (0)
+
+#define FFTCHK(ctx, call)                                                                       \
+  do {                                                                                          \
+    hipfftResult r_ = (call);                                                                   \
+    if (r_ != HIPFFT_SUCCESS) {                                                                 \
+      (ctx).err = std::string(#call) + ": hipfft error " + std::to_string((int)r_);             \
+      return EKPNP_ERR_FFT;                                                                     \
+    }                                                                                           \
+  } while (0)
+
+#define NEEDCTX(ctx)                                                                            \
+  if (!(ctx)) return EKPNP_ERR_INVALID;                                                         \
+  Ctx& c = (ctx)->c
+
+static int fail(Ctx& c, const char* msg) {
+  c.err = msg;
+  return EKPNP_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------------------------------
+
+extern "C" int ekpnp_default_params(ekpnp_params* p, int nx, int ny, int nz) {
+  if (!p || nx < 1 || ny < 1 || nz < 4) return EKPNP_ERR_INVALID;
+  std::memset(p, 0, sizeof(*p));
+  // LBM.h:29-118, same literal expressions
+  p->nx = nx; p->ny = ny; p->nz = nz;
+  p->n_lattices = 4;
+  p->pb_iterations = 501;
+  p->dx = 1.0e-6 / 100.0; p->dy = 1.0e-6 / 100.0; p->dz = 1.0e-6 / 100.0;
+  p->Lx = nx * p->dx; p->Ly = ny * p->dy; p->Lz = (nz - 1) * p->dz;
+  p->CFL = 0.01;
+  p->dt = 0.01 * 1.0e-6 / 100.0;
+  p->cs_square = 1.0 / 3.0 / (0.01 * 0.01);
+  p->rho0 = 1000.0;
+  p->chargeinf = 0.01;
+  p->voltage = -5.2574e-3; p->voltage2 = -5.2574e-3;
+  p->Ext = 1.0e4;
+  p->eps = 6.95e-10;
+  p->diffu = 1.0e-8; p->diffun = 1.0e-8;
+  p->nu = 0.889e-6;
+  p->K = 4.245e-7; p->Kn = -4.245e-7;
+  p->D = 0.889e-6; p->Ra = 1; p->TH = 1;
+  p->uw = 0.0; p->exf = 0.0;
+  p->kB = 1.38e-23; p->electron = 1.6e-19; p->roomT = 273.0;
+  p->convertCtoCharge = 9.64e4;
+  p->PB_omega = 0.05;
+  p->V = 1.0 / 12.0; p->VC = 1.0e-6; p->VCn = 1.0e-6; p->VT = 1.0 / 12.0;
+  return EKPNP_OK;
+}
+
+KArgs Ctx::kargs() const {
+  KArgs a{};
+  for (int l = 0; l < MAXL; ++l) {
+    a.A[l] = pop[cur][l];
+    a.B[l] = pop[cur ^ 1][l];
+  }
+  for (int i = 0; i < EKPNP_NFIELDS; ++i) a.fld[i] = fld[i];
+  a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
+  a.nzl = nzl; a.z0 = z0;
+  a.plane = (long long)plane;
+  a.dstride = (long long)(nzl + 2) * (long long)plane;
+  const double cs2 = p.cs_square, dt = p.dt;
+  // relaxation rates, LBM.cu:488-495 (same expression order)
+  const double omega_plus = 1.0 / (p.nu / cs2 / dt + 1.0 / 2.0) / dt;
+  const double omega_minus = 1.0 / (p.V / (p.nu / cs2 / dt) + 1.0 / 2.0) / dt;
+  const double omega_c_minus = 1.0 / (p.diffu / cs2 / dt + 1.0 / 2.0) / dt;
+  const double omega_c_plus = 1.0 / (p.VC / (p.diffu / cs2 / dt) + 1.0 / 2.0) / dt;
+  const double omega_cn_minus = 1.0 / (p.diffun / cs2 / dt + 1.0 / 2.0) / dt;
+  const double omega_cn_plus = 1.0 / (p.VCn / (p.diffun / cs2 / dt) + 1.0 / 2.0) / dt;
+  const double omega_T_minus = 1.0 / (p.D / cs2 / dt + 1.0 / 2.0) / dt;
+  const double omega_T_plus = 1.0 / (p.VT / (p.D / cs2 / dt) + 1.0 / 2.0) / dt;
+  a.wp[0] = omega_plus * dt;    a.wm[0] = omega_minus * dt;     // LBM.cu:1700-1707
+  a.wp[1] = omega_c_plus * dt;  a.wm[1] = omega_c_minus * dt;
+  a.wp[2] = omega_cn_plus * dt; a.wm[2] = omega_cn_minus * dt;
+  a.wp[3] = omega_T_plus * dt;  a.wm[3] = omega_T_minus * dt;
+  a.mob[0] = 0.0; a.mob[1] = p.K; a.mob[2] = p.Kn; a.mob[3] = 0.0;
+  a.sp = 1.0 - 0.5 * dt * omega_plus;   // LBM.cu:1660-1661
+  a.sm = 1.0 - 0.5 * dt * omega_minus;
+  a.cflinv = 1.0 / p.CFL;               // LBM.cu:1112
+  a.inv_cs2 = 1.0 / cs2;
+  a.cflinv2 = a.cflinv * a.cflinv / cs2;  // LBM.cu:1115
+  a.dt = dt;
+  a.F = p.convertCtoCharge; a.Ext = p.Ext; a.exf = p.exf;
+  a.rho0 = p.rho0; a.Ra = p.Ra; a.nu = p.nu; a.D = p.D;
+  a.buoy_rho0 = 0.0;
+  a.TH = p.TH;
+  a.uw_multi = 2.0 * p.rho0 * p.uw / cs2 / p.CFL;  // LBM.cu:1896-1898 without the weight
+  return a;
+}
+
+PArgs Ctx::pargs() const {
+  PArgs a{};
+  for (int i = 0; i < EKPNP_NFIELDS; ++i) a.fld[i] = fld[i];
+  a.work = work; a.spec = spec; a.cprime = cprime;
+  a.phi_lo = phi_halo[2]; a.phi_hi = phi_halo[3];
+  a.nx = p.nx; a.ny = p.ny; a.nz = p.nz; a.nxh = nxh; a.nzl = nzl; a.z0 = z0;
+  a.plane = (long long)plane;
+  a.F = p.convertCtoCharge; a.eps = p.eps; a.voltage = p.voltage; a.voltage2 = p.voltage2;
+  a.inv_dz2 = 1.0 / p.dz / p.dz;
+  a.dx = p.dx; a.dy = p.dy; a.dz = p.dz;
+  a.inv_nxny = 1.0 / ((double)p.nx * (double)p.ny);
+  return a;
+}
+
+static int dev_alloc(Ctx& c, void** ptr, size_t bytes) {
+  HIPCHK(c, hipMalloc(ptr, bytes));
+  c.bytes += bytes;
+  return EKPNP_OK;
+}
+
+static int validate(const ekpnp_params* p, int rank, int nranks, std::string& err) {
+  if (!p) { err = "params is NULL"; return EKPNP_ERR_INVALID; }
+  if (p->nx < 1 || p->ny < 1 || p->nz < 4) { err = "grid must be at least 1 x 1 x 4"; return EKPNP_ERR_INVALID; }
+  if (p->n_lattices != 1 && p->n_lattices != 3 && p->n_lattices != 4) { err = "n_lattices must be 1, 3 or 4"; return EKPNP_ERR_INVALID; }
+  if (p->n_lattices < 4 && p->Ra != 0.0) { err = "n_lattices < 4 requires Ra == 0 (temperature feeds the buoyancy force, LBM.cu:637)"; return EKPNP_ERR_INVALID; }
+  if (p->n_lattices == 1 && p->chargeinf != 0.0) { err = "n_lattices == 1 requires chargeinf == 0"; return EKPNP_ERR_INVALID; }
+  if (nranks < 1 || rank < 0 || rank >= nranks) { err = "bad rank/nranks"; return EKPNP_ERR_INVALID; }
+  if (p->nz % nranks != 0) { err = "nz must be divisible by nranks"; return EKPNP_ERR_INVALID; }
+  if (nranks > 1 && p->nz / nranks < 4) { err = "each z slab needs at least 4 planes"; return EKPNP_ERR_INVALID; }
+  if (!(p->dx > 0 && p->dy > 0 && p->dz > 0 && p->dt > 0 && p->CFL > 0 && p->cs_square > 0 && p->Lx > 0 && p->Ly > 0 && p->Lz > 0)) {
+    err = "dx, dy, dz, dt, CFL, cs_square, Lx, Ly, Lz must be positive"; return EKPNP_ERR_INVALID;
+  }
+  if (p->pb_iterations < 0) { err = "pb_iterations must be >= 0"; return EKPNP_ERR_INVALID; }
+  return EKPNP_OK;
+}
+
+static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** out) {
+  if (!out) { g_create_err = "out is NULL"; return EKPNP_ERR_INVALID; }
+  *out = nullptr;
+  int rc = validate(p, rank, nranks, g_create_err);
+  if (rc) return rc;
+  ekpnp_ctx* h = new (std::nothrow) ekpnp_ctx();
+  if (!h) { g_create_err = "host allocation failed"; return EKPNP_ERR_NOMEM; }
+  Ctx& c = h->c;
+  c.p = *p;
+  c.rank = rank; c.nranks = nranks;
+  c.nzl = p->nz / nranks;
+  c.z0 = rank * c.nzl;
+  c.nxh = p->nx / 2 + 1;
+  c.plane = (size_t)p->nx * p->ny;
+  c.nloc = c.plane * c.nzl;
+  auto bail = [&](int code) {
+    g_create_err = c.err;
+    ekpnp_destroy(h);
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) {
+    c.err = "hipStreamCreate failed (no HIP device?)";
+    return bail(EKPNP_ERR_HIP);
+  }
+  c.own_stream = true;
+  const size_t popbytes = (size_t)Q * (c.nzl + 2) * c.plane * sizeof(double);
+  for (int b = 0; b < 2; ++b)
+    for (int l = 0; l < p->n_lattices; ++l)
+      if ((rc = dev_alloc(c, (void**)&c.pop[b][l], popbytes))) return bail(rc);
+  for (int i = 0; i < EKPNP_NFIELDS; ++i) {
+    if ((rc = dev_alloc(c, (void**)&c.fld[i], c.nloc * sizeof(double)))) return bail(rc);
+    c.fld_owned[i] = true;
+    if (hipMemsetAsync(c.fld[i], 0, c.nloc * sizeof(double), c.stream) != hipSuccess) { c.err = "hipMemsetAsync failed"; return bail(EKPNP_ERR_HIP); }
+  }
+  if ((rc = dev_alloc(c, (void**)&c.work, c.nloc * sizeof(double)))) return bail(rc);
+  if ((rc = dev_alloc(c, (void**)&c.spec, (size_t)c.nzl * p->ny * c.nxh * sizeof(double2)))) return bail(rc);
+  if ((rc = dev_alloc(c, (void**)&c.cprime, (size_t)p->nz * p->ny * c.nxh * sizeof(double)))) return bail(rc);
+  c.halo_doubles = (size_t)p->n_lattices * 9 * c.plane;
+  if (nranks > 1) {
+    for (int k = 0; k < 4; ++k) {
+      if ((rc = dev_alloc(c, (void**)&c.halo[k], c.halo_doubles * sizeof(double)))) return bail(rc);
+      if ((rc = dev_alloc(c, (void**)&c.phi_halo[k], c.plane * sizeof(double)))) return bail(rc);
+    }
+  }
+  // batched 2-D real transforms over the owned planes (replaces cufftPlan3d, main.cu:112)
+  {
+    int n[2] = {p->ny, p->nx};
+    hipfftResult r = hipfftPlanMany(&c.plan_fwd, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, c.nzl);
+    if (r == HIPFFT_SUCCESS) r = hipfftPlanMany(&c.plan_inv, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, c.nzl);
+    if (r != HIPFFT_SUCCESS) { c.err = "hipfftPlanMany failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
+    c.plans = true;
+    hipfftSetStream(c.plan_fwd, c.stream);
+    hipfftSetStream(c.plan_inv, c.stream);
+  }
+  build_cprime(c);
+  if (hipStreamSynchronize(c.stream) != hipSuccess || hipGetLastError() != hipSuccess) { c.err = "device initialisation failed"; return bail(EKPNP_ERR_HIP); }
+  *out = h;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_create(const ekpnp_params* p, ekpnp_ctx** out) { return create_impl(p, 0, 1, out); }
+extern "C" int ekpnp_create_slab(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** out) { return create_impl(p, rank, nranks, out); }
+
+extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
+  if (!ctx) return EKPNP_ERR_INVALID;
+  Ctx& c = ctx->c;
+  if (c.stream) (void)hipStreamSynchronize(c.stream);
+  for (int b = 0; b < 2; ++b)
+    for (int l = 0; l < MAXL; ++l)
+      if (c.pop[b][l]) (void)hipFree(c.pop[b][l]);
+  for (int i = 0; i < EKPNP_NFIELDS; ++i)
+    if (c.fld[i] && c.fld_owned[i]) (void)hipFree(c.fld[i]);
+  if (c.work) (void)hipFree(c.work);
+  if (c.spec) (void)hipFree(c.spec);
+  if (c.cprime) (void)hipFree(c.cprime);
+  for (int k = 0; k < 4; ++k) {
+    if (c.halo[k]) (void)hipFree(c.halo[k]);
+    if (c.phi_halo[k]) (void)hipFree(c.phi_halo[k]);
+  }
+  if (c.plans) { hipfftDestroy(c.plan_fwd); hipfftDestroy(c.plan_inv); }
+  for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+  delete ctx;
+  return EKPNP_OK;
+}
+
+extern "C" const char* ekpnp_last_error(const ekpnp_ctx* ctx) { return ctx ? ctx->c.err.c_str() : g_create_err.c_str(); }
+
+extern "C" int ekpnp_set_stream(ekpnp_ctx* ctx, void* s) {
+  NEEDCTX(ctx);
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  if (c.own_stream) { (void)hipStreamDestroy(c.stream); c.own_stream = false; }
+  c.stream = (hipStream_t)s;
+  FFTCHK(c, hipfftSetStream(c.plan_fwd, c.stream));
+  FFTCHK(c, hipfftSetStream(c.plan_inv, c.stream));
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_synchronize(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_bind_field(ekpnp_ctx* ctx, int id, double* dptr) {
+  NEEDCTX(ctx);
+  if (id < 0 || id >= EKPNP_NFIELDS || !dptr) return fail(c, "bad field id or NULL pointer");
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  HIPCHK(c, hipMemcpy(dptr, c.fld[id], c.nloc * sizeof(double), hipMemcpyDeviceToDevice));
+  if (c.fld_owned[id]) { (void)hipFree(c.fld[id]); c.bytes -= c.nloc * sizeof(double); }
+  c.fld[id] = dptr;
+  c.fld_owned[id] = false;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_field_device_ptr(ekpnp_ctx* ctx, int id, double** dptr) {
+  NEEDCTX(ctx);
+  if (id < 0 || id >= EKPNP_NFIELDS || !dptr) return fail(c, "bad field id or NULL pointer");
+  *dptr = c.fld[id];
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_set_field(ekpnp_ctx* ctx, int id, const double* host) {
+  NEEDCTX(ctx);
+  if (id < 0 || id >= EKPNP_NFIELDS || !host) return fail(c, "bad field id or NULL pointer");
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  HIPCHK(c, hipMemcpy(c.fld[id], host, c.nloc * sizeof(double), hipMemcpyHostToDevice));
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_get_field(ekpnp_ctx* ctx, int id, double* host) {
+  NEEDCTX(ctx);
+  if (id < 0 || id >= EKPNP_NFIELDS || !host) return fail(c, "bad field id or NULL pointer");
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  HIPCHK(c, hipMemcpy(host, c.fld[id], c.nloc * sizeof(double), hipMemcpyDeviceToHost));
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_local_extent(ekpnp_ctx* ctx, int* z0, int* nzl) {
+  NEEDCTX(ctx);
+  if (z0) *z0 = c.z0;
+  if (nzl) *nzl = c.nzl;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_get_time(ekpnp_ctx* ctx, double* t) {
+  NEEDCTX(ctx);
+  if (!t) return fail(c, "NULL pointer");
+  *t = c.t;
+  return EKPNP_OK;
+}
+extern "C" int ekpnp_set_time(ekpnp_ctx* ctx, double t) {
+  NEEDCTX(ctx);
+  c.t = t;
+  return EKPNP_OK;
+}
+
+extern "C" size_t ekpnp_device_bytes(const ekpnp_ctx* ctx) { return ctx ? ctx->c.bytes : 0; }
+
+// ------------------------------------------------------------------------------------------
+// Poisson
+
+static int poisson_single(Ctx& c) {
+  launch_poisson_rhs(c);
+  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.work, (hipfftDoubleComplex*)c.spec));
+  launch_tridiag(c);
+  FFTCHK(c, hipfftExecZ2D(c.plan_inv, (hipfftDoubleComplex*)c.spec, c.work));
+  launch_phi_efield(c);
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_fast_poisson(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.nranks != 1) return fail(c, "ekpnp_fast_poisson on a slab context: use ekpnp_poisson_stage1/2/3 with the halo transport");
+  return poisson_single(c);
+}
+
+// ------------------------------------------------------------------------------------------
+// initial state
+
+extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.nranks != 1) return fail(c, "ekpnp_initialization on a slab context: drive the PB sweeps through the slab host (Poisson needs the transport)");
+  launch_init_fields(c);
+  double* phi_old = nullptr;
+  HIPCHK(c, hipMalloc((void**)&phi_old, c.nloc * sizeof(double)));
+  // LBM.cu:82-86: phi_old <- phi
+  hipError_t e = hipMemcpyAsync(phi_old, c.fld[EKPNP_PHI], c.nloc * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
+  int rc = EKPNP_OK;
+  if (e != hipSuccess) { c.err = "hipMemcpyAsync failed"; rc = EKPNP_ERR_HIP; }
+  for (int i = 0; rc == EKPNP_OK && i < c.p.pb_iterations; ++i) {  // LBM.cu:89-106
+    launch_pbe(c);
+    rc = poisson_single(c);
+    launch_pbe_relax(c, phi_old);
+  }
+  (void)hipStreamSynchronize(c.stream);
+  (void)hipFree(phi_old);
+  if (rc == EKPNP_OK) HIPCHK(c, hipGetLastError());
+  return rc;
+}
+
+extern "C" int ekpnp_init_equilibrium(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  launch_init_equilibrium(c);
+  c.streamed_state = true;
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// time step
+
+static int timing_begin(Ctx& c, hipEvent_t** stop) {
+  *stop = nullptr;
+  if (!c.timing) return EKPNP_OK;
+  if (c.ev_used == c.ev.size()) {
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    c.ev.emplace_back(a, b);
+  }
+  HIPCHK(c, hipEventRecord(c.ev[c.ev_used].first, c.stream));
+  *stop = &c.ev[c.ev_used].second;
+  c.ev_used++;
+  return EKPNP_OK;
+}
+
+// first/last owned plane handled by the bulk kernel (wall planes go to the wall kernel)
+static inline int bulk_begin(const Ctx& c) { return c.z0 == 0 ? 1 : 0; }
+static inline int bulk_end(const Ctx& c) { return (c.z0 + c.nzl == c.p.nz) ? c.nzl - 1 : c.nzl; }
+
+static int collide_range(Ctx& c, int zb, int ze, bool timed) {
+  hipEvent_t* stop = nullptr;
+  if (timed) {
+    int rc = timing_begin(c, &stop);
+    if (rc) return rc;
+  }
+  launch_collide_bulk(c, zb, ze);
+  if (stop) {
+    HIPCHK(c, hipEventRecord(*stop, c.stream));
+    c.timed_nodes = (long long)(ze - zb) * (long long)c.plane;
+  }
+  return EKPNP_OK;
+}
+
+static void finish_collide(Ctx& c) {
+  c.cur ^= 1;
+  c.streamed_state = false;
+}
+
+extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
+  NEEDCTX(ctx);
+  (void)t;  // the reference passes t but never uses it (LBM.cu:483-1846)
+  if (c.nranks != 1) return fail(c, "slab context: use ekpnp_collide_boundary_planes/interior_planes + halo transport");
+  int rc = collide_range(c, bulk_begin(c), bulk_end(c), true);
+  if (rc) return rc;
+  launch_collide_walls(c);
+  finish_collide(c);
+  launch_ghost_wrap(c);  // z-periodic ghost loop of gpu_stream, LBM.cu:1972,1975
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_step(ekpnp_ctx* ctx, int nsteps) {
+  NEEDCTX(ctx);
+  if (nsteps < 0) return fail(c, "nsteps < 0");
+  for (int i = 0; i < nsteps; ++i) {  // main.cu:189-200
+    int rc = ekpnp_stream_collide_save(ctx, c.t);
+    if (rc) return rc;
+    rc = poisson_single(c);
+    if (rc) return rc;
+    c.t = c.t + c.p.dt;
+  }
+  return EKPNP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement hooks
+
+extern "C" int ekpnp_kernel_timing_enable(ekpnp_ctx* ctx, int enable) {
+  NEEDCTX(ctx);
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  c.timing = enable != 0;
+  c.ev_used = 0;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* total_ms, int64_t* nodes_per_launch) {
+  NEEDCTX(ctx);
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  double tot = 0.0;
+  for (size_t i = 0; i < c.ev_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c.ev[i].first, c.ev[i].second));
+    tot += ms;
+  }
+  if (n_launches) *n_launches = (int)c.ev_used;
+  if (total_ms) *total_ms = tot;
+  if (nodes_per_launch) *nodes_per_launch = c.timed_nodes;
+  c.ev_used = 0;
+  return EKPNP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// z-slab interface (filled in by slab.hip once the distributed tridiagonal lands)
+
+extern "C" int ekpnp_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, size_t* n) {
+  NEEDCTX(ctx);
+  if (which < 0 || which > 3 || !dptr || !n) return fail(c, "bad halo buffer id");
+  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  *dptr = c.halo[which];
+  *n = c.halo_doubles;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_phi_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, size_t* n) {
+  NEEDCTX(ctx);
+  if (which < 0 || which > 3 || !dptr || !n) return fail(c, "bad halo buffer id");
+  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  *dptr = c.phi_halo[which];
+  *n = c.plane;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_halo_pack(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  launch_halo_pack(c);
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_halo_unpack(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  launch_halo_unpack(c);
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+static int not_yet(Ctx& c) { return fail(c, "z-slab Poisson stages are not implemented in this build"); }
+extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
+extern "C" int ekpnp_poisson_edge_buffer(ekpnp_ctx* ctx, int, double**, size_t*) { NEEDCTX(ctx); return not_yet(c); }
+extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
+extern "C" int ekpnp_phi_halo_pack(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
+extern "C" int ekpnp_poisson_stage3(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
+extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
+extern "C" int ekpnp_collide_interior_planes(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }

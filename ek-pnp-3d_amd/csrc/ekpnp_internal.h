@@ -1,0 +1,131 @@
+// ekpnp_internal.h — shared between the HIP kernels and the C-ABI host (private).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ekpnp.h"
+
+namespace ekpnp {
+
+constexpr int Q = 27;
+constexpr int MAXL = 4;  // f, h, hn, temp
+
+// D3Q27 velocity set in the reference's numbering (gpu_stream, LBM.cu:1983-2008):
+// population d at node x was at x - c_d before streaming; opposite of odd d is d+1.
+__host__ __device__ constexpr int ex_of(int d) {
+  constexpr int t[Q] = {0, 1, -1, 0, 0, 0, 0, 1, -1, 1, -1, 0, 0, 1, -1, 1, -1, 0, 0, 1, -1, 1, -1, 1, -1, -1, 1};
+  return t[d];
+}
+__host__ __device__ constexpr int ey_of(int d) {
+  constexpr int t[Q] = {0, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, -1, 1, 0, 0, 1, -1, 1, -1, 1, -1, -1, 1, 1, -1};
+  return t[d];
+}
+__host__ __device__ constexpr int ez_of(int d) {
+  constexpr int t[Q] = {0, 0, 0, 0, 0, 1, -1, 0, 0, 1, -1, 1, -1, 0, 0, -1, 1, -1, 1, 1, -1, -1, 1, 1, -1, 1, -1};
+  return t[d];
+}
+__host__ __device__ constexpr int opp_of(int d) { return d == 0 ? 0 : ((d & 1) ? d + 1 : d - 1); }
+__host__ __device__ constexpr double w_of(int d) {
+  return d == 0 ? 8.0 / 27.0 : d <= 6 ? 2.0 / 27.0 : d <= 18 ? 1.0 / 54.0 : 1.0 / 216.0;  // LBM.h:109-112
+}
+
+// The 9 directions that cross a z face upwards / downwards.
+__host__ __device__ constexpr int up_dir(int k) {
+  constexpr int t[9] = {5, 9, 11, 16, 18, 19, 22, 23, 25};
+  return t[k];
+}
+__host__ __device__ constexpr int dn_dir(int k) {
+  constexpr int t[9] = {6, 10, 12, 15, 17, 20, 21, 24, 26};
+  return t[k];
+}
+
+// Everything a kernel needs, passed by value.
+struct KArgs {
+  // population buffers: [Q][nzl+2][ny][nx] per lattice, ghost plane below (zg=0) and above
+  const double* A[MAXL];
+  double* B[MAXL];
+  double* fld[EKPNP_NFIELDS];  // [nzl][ny][nx]
+  int nx, ny, nz;              // global lattice
+  int nzl, z0;                 // owned planes and the global index of the first one
+  long long plane;             // nx*ny
+  long long dstride;           // (nzl+2)*plane
+  // derived physics (host-side, in the reference's expression order, LBM.cu:488-495,1660-1661)
+  double wp[MAXL], wm[MAXL];   // omega_plus*dt / omega_minus*dt per lattice
+  double mob[MAXL];            // drift mobility: 0, K, Kn, 0
+  double sp, sm;               // 1 - dt*omega/2
+  double cflinv, inv_cs2, cflinv2, dt;
+  double F, Ext, exf, buoy_rho0, Ra, nu, D;
+  double TH, uw_multi;         // uw_multi = 2*rho0*uw/cs_square/CFL (times w_d in the kernel)
+  double rho0;
+};
+
+struct PArgs {
+  double* fld[EKPNP_NFIELDS];
+  double* work;                // real [nzl][ny][nx]
+  double2* spec;               // complex [nzl][ny][nxh]
+  const double* cprime;        // Thomas table [nz][ny][nxh] (global z index)
+  const double* phi_lo;        // phi plane below / above the slab (slab mode), may be null
+  const double* phi_hi;
+  int nx, ny, nz, nxh, nzl, z0;
+  long long plane;
+  double F, eps, voltage, voltage2, inv_dz2, dx, dy, dz, inv_nxny;
+};
+
+struct Ctx;
+
+// lbm_kernels.hip
+void launch_init_fields(Ctx&);
+void launch_pbe(Ctx&);
+void launch_pbe_relax(Ctx&, double* phi_old);
+void launch_init_equilibrium(Ctx&);
+void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
+void launch_collide_walls(Ctx&);
+void launch_ghost_wrap(Ctx&);
+void launch_halo_pack(Ctx&);
+void launch_halo_unpack(Ctx&);
+// poisson.hip
+void build_cprime(Ctx&);
+void launch_poisson_rhs(Ctx&);
+void launch_tridiag(Ctx&);
+void launch_phi_efield(Ctx&);
+
+struct Ctx {
+  ekpnp_params p{};
+  int rank = 0, nranks = 1;
+  int nzl = 0, z0 = 0, nxh = 0;
+  size_t plane = 0, nloc = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  double* pop[2][MAXL] = {};   // [buffer][lattice]
+  int cur = 0;                 // buffer holding the current state
+  bool streamed_state = true;  // true: pop[cur] holds X1 (post-stream, e.g. fresh equilibrium);
+                               // false: pop[cur] holds post-collision populations (pull next)
+  double* fld[EKPNP_NFIELDS] = {};
+  bool fld_owned[EKPNP_NFIELDS] = {};
+  double* work = nullptr;
+  double2* spec = nullptr;
+  double* cprime = nullptr;
+  double* halo[4] = {};        // send-down, send-up, recv-from-below, recv-from-above
+  size_t halo_doubles = 0;
+  double* phi_halo[4] = {};
+  hipfftHandle plan_fwd = 0, plan_inv = 0;
+  bool plans = false;
+  double t = 0.0;
+  size_t bytes = 0;
+  // kernel timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t ev_used = 0;
+  long long timed_nodes = 0;
+  std::string err;
+
+  KArgs kargs() const;
+  PArgs pargs() const;
+};
+
+}  // namespace ekpnp

@@ -1,0 +1,583 @@
+// lbm_kernels.hip — hand-written gfx950 kernels for the LBM half of the hot path.
+//
+// Replaces the four launches of stream_collide_save (LBM.cu:465-481):
+//   gpu_collide_save (LBM.cu:483-1846), gpu_boundary (1848-1961), gpu_stream (1963-2093),
+//   gpu_bc_charge (2095-2416)
+// by ONE pull-stream + collide pass over double-buffered populations, plus a small kernel for
+// the two wall planes.  The state kept between steps is the POST-collision population set
+// (what the reference holds in f2/h2/hn2/temp2 after gpu_boundary); the pull in the next step
+// performs gpu_stream, and the wall kernel performs gpu_bc_charge on the fly.
+//
+// Mapping to CDNA4: a workgroup is NL wave64s over the same 64 consecutive x nodes; wave l
+// owns lattice l (f, h, hn, temp), so each lane holds 27 FP64 populations (54 VGPRs) instead
+// of 108.  The waves exchange their seven moments through 3.5 KB of LDS, then every wave
+// collides its own lattice.  All 27 loads and 27 stores of a wave are 512-byte contiguous row
+// segments (x is the fastest index, LBM.cu:27-30); row bases are wave-uniform (SGPR) and only
+// the three x offsets live in VGPRs.
+#include <type_traits>
+#include <utility>
+
+#include "ekpnp_internal.h"
+
+namespace ekpnp {
+
+template <int I, int N, int S, class Fn>
+__device__ __forceinline__ void static_for(Fn&& fn) {
+  if constexpr (I < N) {
+    fn(std::integral_constant<int, I>{});
+    static_for<I + S, N, S>(fn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// moments, LBM.cu:621-644 (same summation order as the reference)
+
+__device__ __forceinline__ double sum27(const double (&f)[Q]) {
+  double s = f[0];
+#pragma unroll
+  for (int d = 1; d < Q; ++d) s = s + f[d];
+  return s;
+}
+__device__ __forceinline__ void momentum(const double (&f)[Q], double& jx, double& jy, double& jz) {
+  jx = (f[1] + f[7] + f[9] + f[13] + f[15] + f[19] + f[21] + f[23] + f[26]) -
+       (f[2] + f[8] + f[10] + f[14] + f[16] + f[20] + f[22] + f[24] + f[25]);
+  jy = (f[3] + f[7] + f[11] + f[14] + f[17] + f[19] + f[21] + f[24] + f[25]) -
+       (f[4] + f[8] + f[12] + f[13] + f[18] + f[20] + f[22] + f[23] + f[26]);
+  jz = (f[5] + f[9] + f[11] + f[16] + f[18] + f[19] + f[22] + f[23] + f[25]) -
+       (f[6] + f[10] + f[12] + f[15] + f[17] + f[20] + f[21] + f[24] + f[26]);
+}
+
+struct Force {
+  double x, y, z;
+};
+
+// body force, LBM.cu:635-637
+__device__ __forceinline__ Force body_force(const KArgs& a, double c, double cn, double T, double Ex, double Ey, double Ez) {
+  Force F;
+  const double q = a.F * (c - cn);
+  F.x = q * (Ex + a.Ext) + a.exf;
+  F.y = q * Ey;
+  F.z = q * Ez + a.rho0 * T * a.Ra * a.nu * a.D;
+  return F;
+}
+
+// ------------------------------------------------------------------------------------------
+// TRT collision of the fluid lattice with Guo forcing, LBM.cu:830-1845 (f rows).
+// Algebraically the reference's formulas, written per (d, opp d) pair:
+//   eq+ = w rho (omusq + t^2/2), eq- = w rho t, t = c_d.u/cs^2
+//   F+  = w/cs^2 (-u.F + (e.u)(e.F) cflinv2),  F- = w/cs^2 cflinv (e.F)
+//   out_d = f_d - [wp (f+ - eq+) + wm (f- - eq-)] + dt [sp F+ + sm F-]
+template <class Store>
+__device__ __forceinline__ void collide_fluid(const KArgs& a, const double (&f)[Q], double rho, double ux, double uy, double uz,
+                                              const Force& F, Store&& store) {
+  const double wp = a.wp[0], wm = a.wm[0];
+  const double omusq = 1.0 - 0.5 * (ux * ux + uy * uy + uz * uz) * a.inv_cs2;
+  const double ts = a.inv_cs2 * a.cflinv;
+  const double uF = ux * F.x + uy * F.y + uz * F.z;
+  const double dsp = a.dt * a.sp, dsm = a.dt * a.sm;
+  {
+    const double e0 = w_of(0) * rho * omusq;
+    const double F0 = -(w_of(0) * a.inv_cs2) * uF;
+    store(std::integral_constant<int, 0>{}, f[0] - wp * (f[0] - e0) + dsp * F0);
+  }
+  static_for<1, Q, 2>([&](auto ic) {
+    constexpr int d = decltype(ic)::value;
+    constexpr int cx = ex_of(d), cy = ey_of(d), cz = ez_of(d);
+    constexpr double w = w_of(d);
+    const double eu = cx * ux + cy * uy + cz * uz;
+    const double eF = cx * F.x + cy * F.y + cz * F.z;
+    const double t = eu * ts;
+    const double wr = w * rho;
+    const double ep = wr * (omusq + 0.5 * t * t);
+    const double em = wr * t;
+    const double fp = 0.5 * (f[d] + f[d + 1]);
+    const double fm = 0.5 * (f[d] - f[d + 1]);
+    const double Fp = (w * a.inv_cs2) * (eu * eF * a.cflinv2 - uF);
+    const double Fm = (w * a.inv_cs2) * a.cflinv * eF;
+    const double sym = wp * (fp - ep) - dsp * Fp;
+    const double asym = wm * (fm - em) - dsm * Fm;
+    store(std::integral_constant<int, d>{}, f[d] - sym - asym);
+    store(std::integral_constant<int, d + 1>{}, f[d + 1] - sym + asym);
+  });
+}
+
+// TRT collision of an advected scalar (h, hn, temp rows of LBM.cu:830-1845): equilibrium
+// velocity v = u + mobility*E (ions) or u (temperature); no source term.
+template <class Store>
+__device__ __forceinline__ void collide_scalar(const KArgs& a, const double (&f)[Q], double m, double vx, double vy, double vz,
+                                               double wp, double wm, Store&& store) {
+  const double omusq = 1.0 - 0.5 * (vx * vx + vy * vy + vz * vz) * a.inv_cs2;
+  const double ts = a.inv_cs2 * a.cflinv;
+  {
+    const double e0 = w_of(0) * m * omusq;
+    store(std::integral_constant<int, 0>{}, f[0] - wp * (f[0] - e0));
+  }
+  static_for<1, Q, 2>([&](auto ic) {
+    constexpr int d = decltype(ic)::value;
+    constexpr int cx = ex_of(d), cy = ey_of(d), cz = ez_of(d);
+    constexpr double w = w_of(d);
+    const double t = (cx * vx + cy * vy + cz * vz) * ts;
+    const double wr = w * m;
+    const double ep = wr * (omusq + 0.5 * t * t);
+    const double em = wr * t;
+    const double fp = 0.5 * (f[d] + f[d + 1]);
+    const double fm = 0.5 * (f[d] - f[d + 1]);
+    const double sym = wp * (fp - ep);
+    const double asym = wm * (fm - em);
+    store(std::integral_constant<int, d>{}, f[d] - sym - asym);
+    store(std::integral_constant<int, d + 1>{}, f[d + 1] - sym + asym);
+  });
+}
+
+// equilibrium populations, LBM.cu:207-462 / 850-1103
+__device__ __forceinline__ void equilibrium(const KArgs& a, double m, double vx, double vy, double vz, double (&eq)[Q]) {
+  const double omusq = 1.0 - 0.5 * (vx * vx + vy * vy + vz * vz) * a.inv_cs2;
+  const double ts = a.inv_cs2 * a.cflinv;
+  static_for<0, Q, 1>([&](auto ic) {
+    constexpr int d = decltype(ic)::value;
+    const double t = (ex_of(d) * vx + ey_of(d) * vy + ez_of(d) * vz) * ts;
+    eq[d] = (w_of(d) * m) * (omusq + t * (1.0 + 0.5 * t));
+  });
+}
+
+// ------------------------------------------------------------------------------------------
+// bulk kernel: every owned plane that is not a wall plane
+
+template <int NL, bool PULL>
+__global__ void __launch_bounds__(64 * NL) k_collide_bulk(const KArgs a, const int zl_begin, const int nrows, const int nxb) {
+  __shared__ double mom[7][64];
+  // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs, so give each XCD
+  // whole x rows (consecutive `slot`s of one XCD walk along x, then to the next row): the
+  // cache lines straddled by two neighbouring 64-node segments are then served by one L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int row = (slot / nxb) * 8 + xcd;
+  const int xb = slot - (slot / nxb) * nxb;
+  if (row >= nrows) return;  // whole workgroup leaves together
+  const int y = row % a.ny;
+  const int zl = zl_begin + row / a.ny;
+  const int zg = zl + 1;
+  const int lane = threadIdx.x & 63;
+  const int lat = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x = xb * 64 + lane;
+  const bool act = x < a.nx;
+  const int xc = act ? x : a.nx - 1;
+  // source x for c_x = -1, 0, +1 (pull: x - c_x, periodic, LBM.cu:1970-1975)
+  const unsigned xs[3] = {(unsigned)(xc + 1 == a.nx ? 0 : xc + 1), (unsigned)xc, (unsigned)(xc == 0 ? a.nx - 1 : xc - 1)};
+  const int ys[3] = {y + 1 == a.ny ? 0 : y + 1, y, y == 0 ? a.ny - 1 : y - 1};
+
+  const double* __restrict__ src = a.A[lat];
+  double f[Q];
+  static_for<0, Q, 1>([&](auto ic) {
+    constexpr int d = decltype(ic)::value;
+    constexpr int cx = PULL ? ex_of(d) : 0, cy = PULL ? ey_of(d) : 0, cz = PULL ? ez_of(d) : 0;
+    const double* rowp = src + (long long)d * a.dstride + ((long long)(zg - cz) * a.ny + ys[cy + 1]) * (long long)a.nx;
+    f[d] = rowp[xs[cx + 1]];
+  });
+
+  if constexpr (NL > 1) {
+    if (lat == 0) {
+      double jx, jy, jz;
+      momentum(f, jx, jy, jz);
+      mom[0][lane] = sum27(f);
+      mom[1][lane] = jx;
+      mom[2][lane] = jy;
+      mom[3][lane] = jz;
+    } else {
+      mom[3 + lat][lane] = sum27(f);
+    }
+    __syncthreads();
+  }
+  double rho, jx, jy, jz, c = 0.0, cn = 0.0, T = 0.0, Ex = 0.0, Ey = 0.0, Ez = 0.0;
+  const long long sidx = ((long long)zl * a.ny + y) * (long long)a.nx + xc;
+  if constexpr (NL > 1) {
+    rho = mom[0][lane];
+    jx = mom[1][lane];
+    jy = mom[2][lane];
+    jz = mom[3][lane];
+    c = mom[4][lane];
+    cn = mom[5][lane];
+    if constexpr (NL > 3) T = mom[6][lane];
+    Ex = a.fld[EKPNP_EX][sidx];
+    Ey = a.fld[EKPNP_EY][sidx];
+    Ez = a.fld[EKPNP_EZ][sidx];
+  } else {
+    rho = sum27(f);
+    momentum(f, jx, jy, jz);
+  }
+  const Force F = body_force(a, c, cn, T, Ex, Ey, Ez);
+  const double rhoinv = 1.0 / rho;
+  const double hdt = a.dt * 0.5;
+  const double ux = rhoinv * (jx * a.cflinv + F.x * hdt);  // LBM.cu:639-644
+  const double uy = rhoinv * (jy * a.cflinv + F.y * hdt);
+  const double uz = rhoinv * (jz * a.cflinv + F.z * hdt);
+
+  double* __restrict__ dst = a.B[lat];
+  const long long orow = ((long long)zg * a.ny + y) * (long long)a.nx + xc;
+  auto store = [&](auto ic, double v) {
+    constexpr int d = decltype(ic)::value;
+    if (act) dst[(long long)d * a.dstride + orow] = v;
+  };
+  if (lat == 0) {
+    if (act) {  // LBM.cu:807-810
+      a.fld[EKPNP_RHO][sidx] = rho;
+      a.fld[EKPNP_UX][sidx] = ux;
+      a.fld[EKPNP_UY][sidx] = uy;
+      a.fld[EKPNP_UZ][sidx] = uz;
+    }
+    collide_fluid(a, f, rho, ux, uy, uz, F, store);
+  } else {
+    const double m = lat == 1 ? c : lat == 2 ? cn : T;
+    if (act) a.fld[lat == 1 ? EKPNP_C : lat == 2 ? EKPNP_CN : EKPNP_T][sidx] = m;  // LBM.cu:811-813
+    const double k = a.mob[lat];
+    collide_scalar(a, f, m, ux + k * Ex, uy + k * Ey, uz + k * Ez, a.wp[lat], a.wm[lat], store);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wall planes (global z = 0 and z = NZ-1): one thread per wall node, lattices in sequence.
+
+// pre-collision populations of lattice L at a node, as gpu_stream would have left them
+template <bool PULL>
+__device__ __forceinline__ void gather(const KArgs& a, const double* __restrict__ src, int x, int y, int zg, double (&f)[Q]) {
+  const int xs[3] = {x + 1 == a.nx ? 0 : x + 1, x, x == 0 ? a.nx - 1 : x - 1};
+  const int ys[3] = {y + 1 == a.ny ? 0 : y + 1, y, y == 0 ? a.ny - 1 : y - 1};
+  static_for<0, Q, 1>([&](auto ic) {
+    constexpr int d = decltype(ic)::value;
+    constexpr int cx = PULL ? ex_of(d) : 0, cy = PULL ? ey_of(d) : 0, cz = PULL ? ez_of(d) : 0;
+    f[d] = src[(long long)d * a.dstride + ((long long)(zg - cz) * a.ny + ys[cy + 1]) * (long long)a.nx + xs[cx + 1]];
+  });
+}
+
+// pre-collision populations of a scalar lattice AT A WALL NODE: what gpu_bc_charge
+// (LBM.cu:2095-2416) leaves in h1/hn1/temp1 (+temp0) after gpu_stream: the node's own
+// post-collision populations swapped (ions) or negated-and-swapped plus 2 TH w (temperature).
+template <bool PULL>
+__device__ __forceinline__ void wall_scalar_pops(const KArgs& a, int lat, const double* __restrict__ src, int x, int y, int zg,
+                                                 double TH_wall, double (&f)[Q]) {
+  if constexpr (!PULL) {
+    gather<false>(a, src, x, y, zg, f);
+  } else {
+    const long long o = ((long long)zg * a.ny + y) * (long long)a.nx + x;
+    static_for<0, Q, 1>([&](auto ic) {
+      constexpr int d = decltype(ic)::value;
+      const double v = src[(long long)opp_of(d) * a.dstride + o];
+      f[d] = (lat == 3) ? (-v + 2.0 * TH_wall * w_of(d)) : v;
+    });
+  }
+}
+
+template <int NL, bool PULL>
+__global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int top) {
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= a.nx) return;
+  const int zl = top ? a.nzl - 1 : 0;
+  const int zg = zl + 1;
+  const double TH_wall = top ? 0.0 : a.TH;  // LBM.cu:2226-2229 vs 2357-2412
+  const long long sidx = ((long long)zl * a.ny + y) * (long long)a.nx + x;
+  const long long orow = ((long long)zg * a.ny + y) * (long long)a.nx + x;
+
+  double f[Q];
+  gather<PULL>(a, a.A[0], x, y, zg, f);
+  const double rho = sum27(f);
+  double jx, jy, jz;
+  momentum(f, jx, jy, jz);
+  double ms[3] = {0.0, 0.0, 0.0};  // c, cn, T
+  {
+    double g[Q];
+    if constexpr (NL > 1) {
+      wall_scalar_pops<PULL>(a, 1, a.A[1], x, y, zg, TH_wall, g);
+      ms[0] = sum27(g);
+      wall_scalar_pops<PULL>(a, 2, a.A[2], x, y, zg, TH_wall, g);
+      ms[1] = sum27(g);
+    }
+    if constexpr (NL > 3) {
+      wall_scalar_pops<PULL>(a, 3, a.A[3], x, y, zg, TH_wall, g);
+      ms[2] = sum27(g);
+    }
+  }
+  double Ex = 0.0, Ey = 0.0, Ez = 0.0;
+  if constexpr (NL > 1) {
+    Ex = a.fld[EKPNP_EX][sidx];
+    Ey = a.fld[EKPNP_EY][sidx];
+    Ez = a.fld[EKPNP_EZ][sidx];
+  }
+  const double rhoinv = 1.0 / rho;
+  const double hdt = a.dt * 0.5;
+  double ux, uy, uz;
+  if (!top) {
+    // z == 0 override, LBM.cu:663-801: minus the velocity formula evaluated with node z=1's
+    // pre-collision populations, field and moments, but with 1/rho of node z=0 (LBM.cu:780).
+    double g[Q];
+    gather<PULL>(a, a.A[0], x, y, zg + 1, g);
+    double j1x, j1y, j1z;
+    momentum(g, j1x, j1y, j1z);
+    double m1[3] = {0.0, 0.0, 0.0};
+    double E1x = 0.0, E1y = 0.0, E1z = 0.0;
+    if constexpr (NL > 1) {
+      gather<PULL>(a, a.A[1], x, y, zg + 1, g);
+      m1[0] = sum27(g);
+      gather<PULL>(a, a.A[2], x, y, zg + 1, g);
+      m1[1] = sum27(g);
+      const long long s1 = sidx + a.plane;
+      E1x = a.fld[EKPNP_EX][s1];
+      E1y = a.fld[EKPNP_EY][s1];
+      E1z = a.fld[EKPNP_EZ][s1];
+    }
+    if constexpr (NL > 3) {
+      gather<PULL>(a, a.A[3], x, y, zg + 1, g);
+      m1[2] = sum27(g);
+    }
+    const Force F1 = body_force(a, m1[0], m1[1], m1[2], E1x, E1y, E1z);
+    ux = -rhoinv * (j1x * a.cflinv + F1.x * hdt);
+    uy = -rhoinv * (j1y * a.cflinv + F1.y * hdt);
+    uz = -rhoinv * (j1z * a.cflinv + F1.z * hdt);
+  } else {
+    const Force F = body_force(a, ms[0], ms[1], ms[2], Ex, Ey, Ez);
+    ux = rhoinv * (jx * a.cflinv + F.x * hdt);
+    uy = rhoinv * (jy * a.cflinv + F.y * hdt);
+    uz = rhoinv * (jz * a.cflinv + F.z * hdt);
+  }
+  a.fld[EKPNP_RHO][sidx] = rho;
+  a.fld[EKPNP_UX][sidx] = ux;
+  a.fld[EKPNP_UY][sidx] = uy;
+  a.fld[EKPNP_UZ][sidx] = uz;
+  if constexpr (NL > 1) {
+    a.fld[EKPNP_C][sidx] = ms[0];
+    a.fld[EKPNP_CN][sidx] = ms[1];
+  }
+  if constexpr (NL > 3) a.fld[EKPNP_T][sidx] = ms[2];
+
+  // fluid: gpu_boundary (LBM.cu:1848-1961) discards the wall collision: f0 <- pre-collision f0,
+  // f2[d] <- pre-collision f1[opp d] (+ moving-wall terms on the upper plate).
+  {
+    double* __restrict__ dst = a.B[0];
+    static_for<0, Q, 1>([&](auto ic) {
+      constexpr int d = decltype(ic)::value;
+      double v = f[opp_of(d)];
+      if (top && d != 0) {
+        constexpr int sgn = (ex_of(d) > 0 || d == 3) ? 1 : (ex_of(d) < 0 ? -1 : 0);  // LBM.cu:1902-1927
+        if constexpr (sgn != 0) v = v + sgn * (a.uw_multi * w_of(d));
+      }
+      dst[(long long)d * a.dstride + orow] = v;
+    });
+  }
+  // ions and temperature collide on the wall like anywhere else (their post-collision values
+  // are what gpu_bc_charge reflects in the next step).
+  if constexpr (NL > 1) {
+    static_for<1, NL, 1>([&](auto lc) {
+      constexpr int lat = decltype(lc)::value;
+      double g[Q];
+      wall_scalar_pops<PULL>(a, lat, a.A[lat], x, y, zg, TH_wall, g);
+      double* __restrict__ dst = a.B[lat];
+      auto store = [&](auto ic, double v) {
+        constexpr int d = decltype(ic)::value;
+        dst[(long long)d * a.dstride + orow] = v;
+      };
+      const double k = a.mob[lat];
+      collide_scalar(a, g, ms[lat - 1], ux + k * Ex, uy + k * Ey, uz + k * Ez, a.wp[lat], a.wm[lat], store);
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// z-periodic ghost loop of gpu_stream (LBM.cu:1972,1975) for a single slab, and the slab halo
+// pack/unpack.  Buffers: [lattice][9 dirs][ny][nx].
+
+__global__ void k_ghost_wrap(double* p0, double* p1, double* p2, double* p3, int nl, long long plane, long long dstride, int nzl) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plane) return;
+  const int k = blockIdx.y;
+  double* pp[MAXL] = {p0, p1, p2, p3};
+  for (int l = 0; l < nl; ++l) {
+    double* p = pp[l];
+    const int du = up_dir(k), dd = dn_dir(k);
+    p[(long long)du * dstride + i] = p[(long long)du * dstride + (long long)nzl * plane + i];              // ghost below <- top plane
+    p[(long long)dd * dstride + (long long)(nzl + 1) * plane + i] = p[(long long)dd * dstride + plane + i];  // ghost above <- bottom plane
+  }
+}
+
+__global__ void k_halo_pack(const double* p0, const double* p1, const double* p2, const double* p3, int nl, long long plane,
+                            long long dstride, int nzl, double* send_dn, double* send_up) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plane) return;
+  const int k = blockIdx.y;
+  const double* pp[MAXL] = {p0, p1, p2, p3};
+  for (int l = 0; l < nl; ++l) {
+    const double* p = pp[l];
+    send_up[((long long)l * 9 + k) * plane + i] = p[(long long)up_dir(k) * dstride + (long long)nzl * plane + i];
+    send_dn[((long long)l * 9 + k) * plane + i] = p[(long long)dn_dir(k) * dstride + plane + i];
+  }
+}
+
+__global__ void k_halo_unpack(double* p0, double* p1, double* p2, double* p3, int nl, long long plane, long long dstride, int nzl,
+                              const double* recv_lo, const double* recv_hi) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plane) return;
+  const int k = blockIdx.y;
+  double* pp[MAXL] = {p0, p1, p2, p3};
+  for (int l = 0; l < nl; ++l) {
+    double* p = pp[l];
+    p[(long long)up_dir(k) * dstride + i] = recv_lo[((long long)l * 9 + k) * plane + i];
+    p[(long long)dn_dir(k) * dstride + (long long)(nzl + 1) * plane + i] = recv_hi[((long long)l * 9 + k) * plane + i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// initial state: gpu_initialization (LBM.cu:111-128), gpu_PBE (139-146), gpu_PBE_phi (131-137),
+// gpu_init_equilibrium (162-463)
+
+__global__ void k_init_fields(KArgs a, double voltage, double Lz, double dz) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)a.nzl * a.plane;
+  if (i >= n) return;
+  const int z = a.z0 + (int)(i / a.plane);
+  a.fld[EKPNP_RHO][i] = a.rho0;
+  a.fld[EKPNP_C][i] = 0.0;
+  a.fld[EKPNP_CN][i] = 0.0;
+  a.fld[EKPNP_PHI][i] = voltage;
+  a.fld[EKPNP_UX][i] = 0.0;
+  a.fld[EKPNP_UY][i] = 0.0;
+  a.fld[EKPNP_UZ][i] = 0.0;
+  a.fld[EKPNP_EX][i] = 0.0;
+  a.fld[EKPNP_EY][i] = 0.0;
+  a.fld[EKPNP_EZ][i] = 0.0;
+  a.fld[EKPNP_T][i] = a.TH * (Lz - dz * z) / Lz;
+}
+
+__global__ void k_pbe(double* c, double* cn, const double* phi, long long n, double chargeinf, double electron, double kB, double roomT) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double fi = phi[i];
+  c[i] = chargeinf * exp(-electron * fi / kB / roomT);
+  cn[i] = chargeinf * exp(electron * fi / kB / roomT);
+}
+
+// phi <- omega*phi + (1-omega)*phi_old; phi_old <- phi   (LBM.cu:98-104 without the host round trip)
+__global__ void k_pbe_relax(double* phi, double* phi_old, long long n, double omega) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = omega * phi[i] + (1.0 - omega) * phi_old[i];
+  phi[i] = v;
+  phi_old[i] = v;
+}
+
+template <int NL>
+__global__ void k_init_equilibrium(KArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)a.nzl * a.plane;
+  if (i >= n) return;
+  const long long o = i + a.plane;  // ghost plane below
+  const double rho = a.fld[EKPNP_RHO][i], ux = a.fld[EKPNP_UX][i], uy = a.fld[EKPNP_UY][i], uz = a.fld[EKPNP_UZ][i];
+  const double Ex = a.fld[EKPNP_EX][i], Ey = a.fld[EKPNP_EY][i], Ez = a.fld[EKPNP_EZ][i];
+  double eq[Q];
+  static_for<0, NL, 1>([&](auto lc) {
+    constexpr int lat = decltype(lc)::value;
+    const double m = lat == 0 ? rho : a.fld[lat == 1 ? EKPNP_C : lat == 2 ? EKPNP_CN : EKPNP_T][i];
+    const double k = a.mob[lat];
+    equilibrium(a, m, ux + k * Ex, uy + k * Ey, uz + k * Ez, eq);
+    double* dst = a.B[lat];
+#pragma unroll
+    for (int d = 0; d < Q; ++d) dst[(long long)d * a.dstride + o] = eq[d];
+  });
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers
+
+static inline dim3 grid1d(long long n, int b) { return dim3((unsigned)((n + b - 1) / b)); }
+
+void launch_init_fields(Ctx& c) {
+  KArgs a = c.kargs();
+  hipLaunchKernelGGL(k_init_fields, grid1d((long long)c.nloc, 256), dim3(256), 0, c.stream, a, c.p.voltage, c.p.Lz, c.p.dz);
+}
+
+void launch_pbe(Ctx& c) {
+  hipLaunchKernelGGL(k_pbe, grid1d((long long)c.nloc, 256), dim3(256), 0, c.stream, c.fld[EKPNP_C], c.fld[EKPNP_CN], c.fld[EKPNP_PHI],
+                     (long long)c.nloc, c.p.chargeinf, c.p.electron, c.p.kB, c.p.roomT);
+}
+
+void launch_pbe_relax(Ctx& c, double* phi_old) {
+  hipLaunchKernelGGL(k_pbe_relax, grid1d((long long)c.nloc, 256), dim3(256), 0, c.stream, c.fld[EKPNP_PHI], phi_old, (long long)c.nloc,
+                     c.p.PB_omega);
+}
+
+void launch_init_equilibrium(Ctx& c) {
+  KArgs a = c.kargs();
+  // write into the CURRENT buffer: kargs() exposes it as A (const); B is the other one
+  for (int l = 0; l < MAXL; ++l) a.B[l] = c.pop[c.cur][l];
+  dim3 g = grid1d((long long)c.nloc, 128), b(128);
+  switch (c.p.n_lattices) {
+    case 1: hipLaunchKernelGGL(k_init_equilibrium<1>, g, b, 0, c.stream, a); break;
+    case 3: hipLaunchKernelGGL(k_init_equilibrium<3>, g, b, 0, c.stream, a); break;
+    default: hipLaunchKernelGGL(k_init_equilibrium<4>, g, b, 0, c.stream, a); break;
+  }
+}
+
+template <int NL>
+static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
+  const int nrows = (zl_end - zl_begin) * c.p.ny;
+  if (nrows <= 0) return;
+  const int nxb = (c.p.nx + 63) / 64;
+  const int rows8 = (nrows + 7) / 8 * 8;
+  dim3 g((unsigned)((long long)rows8 * nxb)), b(64 * NL);
+  if (c.streamed_state)
+    hipLaunchKernelGGL((k_collide_bulk<NL, false>), g, b, 0, c.stream, a, zl_begin, nrows, nxb);
+  else
+    hipLaunchKernelGGL((k_collide_bulk<NL, true>), g, b, 0, c.stream, a, zl_begin, nrows, nxb);
+}
+
+void launch_collide_bulk(Ctx& c, int zl_begin, int zl_end) {
+  KArgs a = c.kargs();
+  switch (c.p.n_lattices) {
+    case 1: bulk_dispatch<1>(c, a, zl_begin, zl_end); break;
+    case 3: bulk_dispatch<3>(c, a, zl_begin, zl_end); break;
+    default: bulk_dispatch<4>(c, a, zl_begin, zl_end); break;
+  }
+}
+
+template <int NL>
+static void wall_dispatch(Ctx& c, const KArgs& a, int top) {
+  dim3 g((unsigned)((c.p.nx + 63) / 64), (unsigned)c.p.ny), b(64);
+  if (c.streamed_state)
+    hipLaunchKernelGGL((k_collide_wall<NL, false>), g, b, 0, c.stream, a, top);
+  else
+    hipLaunchKernelGGL((k_collide_wall<NL, true>), g, b, 0, c.stream, a, top);
+}
+
+void launch_collide_walls(Ctx& c) {
+  KArgs a = c.kargs();
+  for (int top = 0; top < 2; ++top) {
+    const bool owns = top ? (c.z0 + c.nzl == c.p.nz) : (c.z0 == 0);
+    if (!owns) continue;
+    switch (c.p.n_lattices) {
+      case 1: wall_dispatch<1>(c, a, top); break;
+      case 3: wall_dispatch<3>(c, a, top); break;
+      default: wall_dispatch<4>(c, a, top); break;
+    }
+  }
+}
+
+void launch_ghost_wrap(Ctx& c) {
+  double** p = c.pop[c.cur];
+  dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
+  hipLaunchKernelGGL(k_ghost_wrap, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane,
+                     (long long)(c.nzl + 2) * (long long)c.plane, c.nzl);
+}
+
+void launch_halo_pack(Ctx& c) {
+  double** p = c.pop[c.cur];
+  dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
+  hipLaunchKernelGGL(k_halo_pack, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane,
+                     (long long)(c.nzl + 2) * (long long)c.plane, c.nzl, c.halo[0], c.halo[1]);
+}
+
+void launch_halo_unpack(Ctx& c) {
+  double** p = c.pop[c.cur];
+  dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
+  hipLaunchKernelGGL(k_halo_unpack, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane,
+                     (long long)(c.nzl + 2) * (long long)c.plane, c.nzl, c.halo[2], c.halo[3]);
+}
+
+}  // namespace ekpnp

@@ -1,0 +1,247 @@
+"""ctypes binding of libekpnp.so (include/ekpnp.h).
+
+`Solver` mirrors the reference's host step API one to one:
+
+    reference (LBM.h)                      here
+    -------------------------------------  ------------------------------
+    initialization(r,c,cn,fi,u,v,w,...)    Solver.initialization()
+    init_equilibrium(f0,f1,...,temp)       Solver.init_equilibrium()
+    stream_collide_save(f0,...,t,f0bc)     Solver.stream_collide_save(t)
+    fast_Poisson(charge,chargen,kx,ky,kz)  Solver.fast_Poisson()
+    main.cu:189-200 loop body x n          Solver.step(n)
+
+Errors: the reference prints and exit()s (LBM.cu:35-53); here every non-zero status of the
+C ABI raises EkpnpError carrying ekpnp_last_error().
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBNAME = "libekpnp.so"
+
+FIELDS = ["rho", "c", "cn", "phi", "ux", "uy", "uz", "Ex", "Ey", "Ez", "T"]
+FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
+
+
+class EkpnpError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """Mirror of `ekpnp_params` (include/ekpnp.h)."""
+
+    _fields_ = [(n, C.c_int32) for n in ("nx", "ny", "nz", "n_lattices", "pb_iterations", "reserved0")] + [
+        (n, C.c_double)
+        for n in (
+            "Lx Ly Lz dx dy dz CFL dt cs_square rho0 chargeinf voltage voltage2 Ext eps "
+            "diffu diffun nu K Kn D Ra TH uw exf kB electron roomT convertCtoCharge "
+            "PB_omega V VC VCn VT"
+        ).split()
+    ]
+
+    def copy(self) -> "Params":
+        q = Params()
+        C.memmove(C.byref(q), C.byref(self), C.sizeof(Params))
+        return q
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIBNAME)
+
+
+def exported_symbols() -> list:
+    """Names declared `int|size_t|const char* ekpnp_*(` in include/ekpnp.h."""
+    hdr = os.path.join(_HERE, "..", "include", "ekpnp.h")
+    txt = open(hdr).read()
+    return sorted(set(re.findall(r"\b(ekpnp_[a-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libekpnp.so; raises EkpnpError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise EkpnpError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    L = C.CDLL(path)
+    ctx = C.c_void_p
+    i32, dbl, sz = C.c_int, C.c_double, C.c_size_t
+    pd = C.POINTER(C.c_double)
+    sig = {
+        "ekpnp_default_params": (i32, [C.POINTER(Params), i32, i32, i32]),
+        "ekpnp_create": (i32, [C.POINTER(Params), C.POINTER(ctx)]),
+        "ekpnp_create_slab": (i32, [C.POINTER(Params), i32, i32, C.POINTER(ctx)]),
+        "ekpnp_destroy": (i32, [ctx]),
+        "ekpnp_last_error": (C.c_char_p, [ctx]),
+        "ekpnp_set_stream": (i32, [ctx, C.c_void_p]),
+        "ekpnp_synchronize": (i32, [ctx]),
+        "ekpnp_bind_field": (i32, [ctx, i32, C.c_void_p]),
+        "ekpnp_field_device_ptr": (i32, [ctx, i32, C.POINTER(C.c_void_p)]),
+        "ekpnp_set_field": (i32, [ctx, i32, C.c_void_p]),
+        "ekpnp_get_field": (i32, [ctx, i32, C.c_void_p]),
+        "ekpnp_initialization": (i32, [ctx]),
+        "ekpnp_init_equilibrium": (i32, [ctx]),
+        "ekpnp_stream_collide_save": (i32, [ctx, dbl]),
+        "ekpnp_fast_poisson": (i32, [ctx]),
+        "ekpnp_step": (i32, [ctx, i32]),
+        "ekpnp_get_time": (i32, [ctx, pd]),
+        "ekpnp_set_time": (i32, [ctx, dbl]),
+        "ekpnp_local_extent": (i32, [ctx, C.POINTER(i32), C.POINTER(i32)]),
+        "ekpnp_kernel_timing_enable": (i32, [ctx, i32]),
+        "ekpnp_kernel_timing_get": (i32, [ctx, C.POINTER(i32), pd, C.POINTER(C.c_int64)]),
+        "ekpnp_device_bytes": (sz, [ctx]),
+        "ekpnp_halo_buffer": (i32, [ctx, i32, C.POINTER(C.c_void_p), C.POINTER(sz)]),
+        "ekpnp_halo_pack": (i32, [ctx]),
+        "ekpnp_halo_unpack": (i32, [ctx]),
+        "ekpnp_phi_halo_buffer": (i32, [ctx, i32, C.POINTER(C.c_void_p), C.POINTER(sz)]),
+        "ekpnp_poisson_stage1": (i32, [ctx]),
+        "ekpnp_poisson_edge_buffer": (i32, [ctx, i32, C.POINTER(C.c_void_p), C.POINTER(sz)]),
+        "ekpnp_poisson_stage2": (i32, [ctx]),
+        "ekpnp_phi_halo_pack": (i32, [ctx]),
+        "ekpnp_poisson_stage3": (i32, [ctx]),
+        "ekpnp_collide_boundary_planes": (i32, [ctx]),
+        "ekpnp_collide_interior_planes": (i32, [ctx]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def default_params(nx: int, ny: int, nz: int) -> Params:
+    p = Params()
+    rc = load_library().ekpnp_default_params(C.byref(p), nx, ny, nz)
+    if rc:
+        raise EkpnpError(f"ekpnp_default_params({nx},{ny},{nz}) -> {rc}")
+    return p
+
+
+class Solver:
+    """One EK-PNP simulation on the current HIP device (or one z slab of it)."""
+
+    def __init__(self, params: Params, rank: int = 0, nranks: int = 1):
+        self._L = load_library()
+        self.p = params.copy()
+        self._h = C.c_void_p()
+        if nranks == 1:
+            rc = self._L.ekpnp_create(C.byref(self.p), C.byref(self._h))
+        else:
+            rc = self._L.ekpnp_create_slab(C.byref(self.p), rank, nranks, C.byref(self._h))
+        if rc:
+            msg = self._L.ekpnp_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise EkpnpError(f"ekpnp_create failed ({rc}): {msg}")
+        z0, nzl = C.c_int(), C.c_int()
+        self._ck(self._L.ekpnp_local_extent(self._h, C.byref(z0), C.byref(nzl)))
+        self.z0, self.nz_local = z0.value, nzl.value
+        self.shape = (self.nz_local, self.p.ny, self.p.nx)
+        self.rank, self.nranks = rank, nranks
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _ck(self, rc: int):
+        if rc:
+            raise EkpnpError(f"status {rc}: {self._L.ekpnp_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ekpnp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def lib(self):
+        return self._L
+
+    def synchronize(self):
+        self._ck(self._L.ekpnp_synchronize(self._h))
+
+    def set_stream(self, hip_stream: int):
+        self._ck(self._L.ekpnp_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def device_bytes(self) -> int:
+        return int(self._L.ekpnp_device_bytes(self._h))
+
+    # -- fields -----------------------------------------------------------------------------
+    def get_field(self, name: str) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float64)
+        self._ck(self._L.ekpnp_get_field(self._h, FIELD_ID[name], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_field(self, name: str, value):
+        a = np.ascontiguousarray(value, dtype=np.float64).reshape(self.shape)
+        self._ck(self._L.ekpnp_set_field(self._h, FIELD_ID[name], a.ctypes.data_as(C.c_void_p)))
+
+    def fields(self) -> dict:
+        return {n: self.get_field(n) for n in FIELDS}
+
+    def set_fields(self, d: dict):
+        for n, v in d.items():
+            self.set_field(n, v)
+
+    def field_device_ptr(self, name: str) -> int:
+        p = C.c_void_p()
+        self._ck(self._L.ekpnp_field_device_ptr(self._h, FIELD_ID[name], C.byref(p)))
+        return int(p.value)
+
+    def bind_field(self, name: str, device_ptr: int):
+        self._ck(self._L.ekpnp_bind_field(self._h, FIELD_ID[name], C.c_void_p(device_ptr)))
+
+    # -- the reference's host API (LBM.h:159-180) ---------------------------------------------
+    def initialization(self):
+        self._ck(self._L.ekpnp_initialization(self._h))
+
+    def init_equilibrium(self):
+        self._ck(self._L.ekpnp_init_equilibrium(self._h))
+
+    def stream_collide_save(self, t: float = 0.0):
+        self._ck(self._L.ekpnp_stream_collide_save(self._h, float(t)))
+
+    def fast_Poisson(self):
+        self._ck(self._L.ekpnp_fast_poisson(self._h))
+
+    def step(self, n: int = 1):
+        self._ck(self._L.ekpnp_step(self._h, int(n)))
+
+    @property
+    def t(self) -> float:
+        v = C.c_double()
+        self._ck(self._L.ekpnp_get_time(self._h, C.byref(v)))
+        return v.value
+
+    # -- measurement ------------------------------------------------------------------------
+    def kernel_timing(self, enable: bool):
+        self._ck(self._L.ekpnp_kernel_timing_enable(self._h, int(enable)))
+
+    def kernel_timing_get(self):
+        n, ms, nodes = C.c_int(), C.c_double(), C.c_int64()
+        self._ck(self._L.ekpnp_kernel_timing_get(self._h, C.byref(n), C.byref(ms), C.byref(nodes)))
+        return n.value, ms.value, nodes.value

@@ -1,0 +1,102 @@
+"""Generates tests/golden/ref_*.npz from the REFERENCE's own kernels.  Run on the GPU box:
+
+    python tests/golden/make_golden.py gpurun_out/golden
+
+It drives oracle/_ref/ref_driver (built by oracle/build_ref.sh from /root/reference: the
+reference's LBM.cu / poisson.cu kernels compiled for gfx950) on the reference's compile-time
+grid 50x8x51 (LBM.h:32-35) and stores the macroscopic fields as FP64:
+
+  ref_g1.npz  G1: state after initialization() (501 PB sweeps) and after 1/5/20/100 steps
+              of the default, x-y uniform run (z profiles: the fields are uniform in x,y)
+  ref_g2.npz  G2: the closed-form 3-D perturbation of SURVEY.md §8(c) on top of G1's initial
+              state -> fast_Poisson -> init_equilibrium -> 1, 2, 50 steps (full 3-D fields)
+  ref_g5.npz  G5: fast_Poisson alone on random c, cn
+
+Only data is stored (inputs and the reference's outputs); no reference source travels.
+The files written under the output directory are copied into tests/golden/ by hand
+(see DESIGN.md "Oracle").
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+NX, NY, NZ = 50, 8, 51
+SHAPE = (NZ, NY, NX)
+N = NX * NY * NZ
+
+
+def read_bin(path):
+    a = np.fromfile(path, dtype=np.float64)
+    assert a.size == 11 * N, (path, a.size)
+    return {k: a[i * N : (i + 1) * N].reshape(SHAPE).copy() for i, k in enumerate(O.FIELDS)}
+
+
+def write_bin(path, f):
+    np.concatenate([np.ascontiguousarray(f[k], dtype=np.float64).ravel() for k in O.FIELDS]).tofile(path)
+
+
+def main(outdir):
+    os.makedirs(outdir, exist_ok=True)
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    tmp = tempfile.mkdtemp()
+
+    def run(*args):
+        print("+ ref_driver", *args, flush=True)
+        subprocess.check_call([drv, tmp, *args])
+
+    p = O.default_params(NX, NY, NZ)
+    p.Lx, p.Ly, p.Lz = 0.5e-6, 0.08e-6, 0.5e-6
+
+    # ---- G1
+    run("init")
+    g1 = {"marks": np.array([1, 5, 20, 100])}
+    init = read_bin(os.path.join(tmp, "g1_init.bin"))
+    xy_dev = {}
+    for tag, f in [("init", init)] + [(f"step{m}", read_bin(os.path.join(tmp, f"g1_step{m}.bin"))) for m in (1, 5, 20, 100)]:
+        for k, v in f.items():
+            g1[f"{tag}_{k}"] = v
+            xy_dev[f"{tag}_{k}"] = float(np.abs(v - v[:, :1, :1]).max())
+    np.savez_compressed(os.path.join(outdir, "ref_g1_full.npz"), **g1)
+    print("G1 max x-y non-uniformity:", max(xy_dev.values()))
+
+    # ---- G2
+    start = O.perturb_fields(p, init)
+    inp = os.path.join(tmp, "g2_in.bin")
+    write_bin(inp, start)
+    run("fields", inp, "g2", "1", "2", "50")
+    g2 = {"marks": np.array([1, 2, 50])}
+    for k, v in start.items():
+        g2["input_" + k] = v
+    for m in (0, 1, 2, 50):
+        f = read_bin(os.path.join(tmp, f"g2_step{m}.bin"))
+        for k, v in f.items():
+            g2[f"step{m}_{k}"] = v
+    np.savez_compressed(os.path.join(outdir, "ref_g2_full.npz"), **g2)
+
+    # ---- G5
+    rng = np.random.default_rng(5)
+    f5 = {k: np.zeros(SHAPE) for k in O.FIELDS}
+    f5["c"] = 0.01 * (1 + 0.2 * rng.random(SHAPE))
+    f5["cn"] = 0.01 * (1 + 0.2 * rng.random(SHAPE))
+    inp5 = os.path.join(tmp, "g5_in.bin")
+    write_bin(inp5, f5)
+    run("poisson", inp5, "g5")
+    out5 = read_bin(os.path.join(tmp, "g5.bin"))
+    g5 = {}
+    for k, v in f5.items():
+        g5["input_" + k] = v
+    for k in ("phi", "Ex", "Ey", "Ez"):
+        g5["out_" + k] = out5[k]
+    np.savez_compressed(os.path.join(outdir, "ref_g5_full.npz"), **g5)
+    print("golden vectors written to", outdir)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/golden")

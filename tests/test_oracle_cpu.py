@@ -1,0 +1,197 @@
+"""CPU tests of the oracle: known-answer tests that are independent of the reference
+ and - when present - the golden vectors produced by the reference's
+own kernels on an MI355X (tests/golden/ref_*.npz, made by tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+
+def _ref_grid(O):
+    p = O.default_params(50, 8, 51)
+    # literal values of LBM.h:40-42
+    p.Lx, p.Ly, p.Lz = 0.5e-6, 0.08e-6, 0.5e-6
+    return p
+
+
+def test_K1_poiseuille_profile(O):
+    """Steady ux(z) = exf/(2 rho0 nu) (z - zw0)(zw1 - z) with half-way walls."""
+    p = O.default_params(4, 4, 33)
+    p.exf, p.chargeinf, p.Ra, p.TH, p.pb_iterations = 1e9, 0.0, 0.0, 0.0, 2
+    o = O.Oracle(p)
+    o.initialization()
+    o.init_equilibrium()
+    o.step(12000)
+    ux = o.field("ux")[:, 0, 0]
+    z = np.arange(p.nz) * p.dz
+    ana = p.exf / (2 * p.rho0 * p.nu) * (z - 0.5 * p.dz) * ((p.nz - 1.5) * p.dz - z)
+    rel = np.linalg.norm(ux[1:-1] - ana[1:-1]) / np.linalg.norm(ana[1:-1])
+    assert rel < 1e-3  # 7.9e-4 at NZ=33 (Lambda = 1/12 wall slip), SURVEY.md K1
+    assert abs(ux[0] + ux[1]) < 1e-12 * abs(ux[1])  # z==0 override: ux(0) = -ux(1)
+    mass = o.population("f", 0).sum() + o.population("f", 1).sum()
+    assert abs(mass / (p.rho0 * o.n) - 1) < 1e-12
+    assert np.abs(o.field("uy")).max() < 1e-10 and np.abs(o.field("uz")).max() < 1e-10
+
+
+def test_K2_poisson_equals_fft2_plus_tridiagonal(O):
+    """The odd-extension 3-D DFT path == 2-D FFT in x,y + dense FD solve in z."""
+    p = O.default_params(16, 12, 17)
+    o = O.Oracle(p)
+    o.gpu_initialization()
+    rng = np.random.default_rng(0)
+    o.field("c")[...] = 0.01 * (1 + 0.1 * rng.random(o.shape))
+    o.field("cn")[...] = 0.01 * (1 + 0.1 * rng.random(o.shape))
+    o.fast_poisson()
+    phi = o.field("phi")
+    nz = p.nz
+    g = -p.convertCtoCharge * (o.field("c") - o.field("cn")) / p.eps
+    rhs = g[1 : nz - 1].copy()
+    rhs[0] -= p.voltage / p.dz**2
+    rhs[-1] -= p.voltage2 / p.dz**2
+    rh = np.fft.fft2(rhs, axes=(1, 2))
+    kx = 2 * np.pi * np.fft.fftfreq(p.nx, d=p.Lx / p.nx)
+    ky = 2 * np.pi * np.fft.fftfreq(p.ny, d=p.Ly / p.ny)
+    m = nz - 2
+    A = (np.diag(-2 * np.ones(m)) + np.diag(np.ones(m - 1), 1) + np.diag(np.ones(m - 1), -1)) / p.dz**2
+    sol = np.zeros_like(rh)
+    for j in range(p.ny):
+        for i in range(p.nx):
+            sol[:, j, i] = np.linalg.solve(A - (kx[i] ** 2 + ky[j] ** 2) * np.eye(m), rh[:, j, i])
+    ref = np.fft.ifft2(sol, axes=(1, 2)).real
+    assert np.abs(ref - phi[1 : nz - 1]).max() < 1e-13 * np.abs(phi).max()
+    assert np.all(phi[0] == p.voltage) and np.all(phi[-1] == p.voltage2)
+
+
+def test_K2b_poisson_eigenfunction(O):
+    """sin modes are eigenfunctions with the eigenvalue of poisson.cu:176."""
+    p = O.default_params(16, 8, 33)
+    p.voltage = p.voltage2 = 0.0
+    o = O.Oracle(p)
+    o.gpu_initialization()
+    z, y, x = np.meshgrid(np.arange(p.nz), np.arange(p.ny), np.arange(p.nx), indexing="ij")
+    mx, my, mz = 2, 1, 3
+    mode = np.sin(2 * np.pi * mx * x / p.nx) * np.cos(2 * np.pi * my * y / p.ny) * np.sin(np.pi * mz * z / (p.nz - 1))
+    o.field("c")[...] = 1e-3 * mode
+    o.field("cn")[...] = 0.0
+    o.fast_poisson()
+    kz = mz * 2 * np.pi / (2 * (p.nz - 1) * p.dz)
+    mu = 4 / p.dz**2 * np.sin(kz * p.dz / 2) ** 2 + (2 * np.pi * mx / p.Lx) ** 2 + (2 * np.pi * my / p.Ly) ** 2
+    want = p.convertCtoCharge * 1e-3 * mode / p.eps / mu
+    assert np.abs(o.field("phi") - want).max() < 1e-12 * np.abs(want).max()
+
+
+def test_K4_efield_is_central_difference(O):
+    p = O.default_params(10, 6, 9)
+    o = O.Oracle(p)
+    rng = np.random.default_rng(1)
+    phi = rng.standard_normal(o.shape)
+    o.field("phi")[...] = phi
+    o.efield()
+    ex = 0.5 * (np.roll(phi, 1, 2) - np.roll(phi, -1, 2)) / p.dx
+    ey = 0.5 * (np.roll(phi, 1, 1) - np.roll(phi, -1, 1)) / p.dy
+    ez = 0.5 * (np.roll(phi, 1, 0) - np.roll(phi, -1, 0)) / p.dz
+    ez[0], ez[-1] = ez[1], ez[-2]
+    assert np.array_equal(o.field("Ex"), ex) and np.array_equal(o.field("Ey"), ey) and np.array_equal(o.field("Ez"), ez)
+
+
+def test_K3_debye_layer_after_pb_init(O):
+    """Mid-plane potential of the PB initial state vs the linearised Debye-Hueckel value."""
+    p = _ref_grid(O)
+    o = O.Oracle(p)
+    o.initialization()
+    lam = np.sqrt(p.eps * p.kB * p.roomT / p.electron / (2 * p.chargeinf * p.convertCtoCharge))
+    assert abs(lam / p.dz - 9.2) < 0.1
+    H = (p.nz - 1) * p.dz
+    lin = p.voltage / np.cosh(H / (2 * lam))
+    mid = o.field("phi")[p.nz // 2, 0, 0]
+    assert abs(mid - lin) < 0.05 * abs(lin)
+    c, cn = o.field("c"), o.field("cn")
+    assert np.allclose(c * cn, p.chargeinf**2, rtol=1e-12)  # Boltzmann: c*cn = c_inf^2
+
+
+def test_step_is_deterministic_and_finite(O):
+    p = O.default_params(16, 12, 17)
+    p.pb_iterations = 20
+    outs = []
+    for _ in range(2):
+        o = O.Oracle(p)
+        o.initialization()
+        o.set_fields(O.perturb_fields(p, o.fields()))
+        o.fast_poisson()
+        o.init_equilibrium()
+        o.step(5)
+        outs.append(o.fields())
+    for k in outs[0]:
+        assert np.isfinite(outs[0][k]).all()
+        assert np.array_equal(outs[0][k], outs[1][k])
+
+
+def test_subkernels_compose_to_stream_collide_save(O):
+    p = O.default_params(8, 6, 9)
+    p.pb_iterations = 5
+    a, b = O.Oracle(p), O.Oracle(p)
+    for o in (a, b):
+        o.initialization()
+        o.set_fields(O.perturb_fields(p, o.fields()))
+        o.fast_poisson()
+        o.init_equilibrium()
+    a.stream_collide_save()
+    b.collide_save(); b.boundary(); b.stream(); b.bc_charge()
+    for lat in ("f", "h", "hn", "temp"):
+        for w in (0, 1):
+            assert np.array_equal(a.population(lat, w), b.population(lat, w))
+
+
+# ---- golden vectors from the reference's own kernels (made on the GPU box) ----------------
+
+def _need(name):
+    path = golden_path(name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated yet (tests/golden/make_golden.py on the GPU box)")
+    return np.load(path)
+
+
+def test_golden_G1_default_run(O):
+    g = _need("ref_g1.npz")
+    p = _ref_grid(O)
+    o = O.Oracle(p)
+    o.initialization()
+    got = o.fields()
+    want = {k: g["init_" + k] for k in O.FIELDS}
+    err = O.rel_l2({k: got[k] for k in ("phi", "c", "cn", "Ex", "Ey", "Ez", "T", "rho")},
+                   want, {k: v for k, v in O.GROUPS.items() if k != "u"})
+    assert max(err.values()) < float(g["tol_init"]), err
+    o.init_equilibrium()
+    done = 0
+    for mark in (int(m) for m in g["marks"]):
+        o.step(mark - done)
+        done = mark
+        err = O.rel_l2(o.fields(), {k: g[f"step{mark}_{k}"] for k in O.FIELDS})
+        assert max(err.values()) < float(g["tol_steps"]), (mark, err)
+
+
+def test_golden_G2_perturbed_run(O):
+    g = _need("ref_g2.npz")
+    p = _ref_grid(O)
+    o = O.Oracle(p)
+    o.set_fields({k: g["input_" + k] for k in O.FIELDS})
+    o.fast_poisson()
+    o.init_equilibrium()
+    done = 0
+    for mark in (int(m) for m in g["marks"]):
+        o.step(mark - done)
+        done = mark
+        err = O.rel_l2(o.fields(), {k: g[f"step{mark}_{k}"] for k in O.FIELDS})
+        assert max(err.values()) < float(g["tol_steps"]), (mark, err)
+
+
+def test_golden_G5_poisson_alone(O):
+    g = _need("ref_g5.npz")
+    p = _ref_grid(O)
+    o = O.Oracle(p)
+    o.set_fields({k: g["input_" + k] for k in O.FIELDS})
+    o.fast_poisson()
+    err = O.rel_l2(o.fields(), {k: g["out_" + k] for k in ("phi", "Ex", "Ey", "Ez")}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
+    assert max(err.values()) < float(g["tol"]), err

@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py — MLUPS of the full EK-PNP step (stream_collide_save + fast_Poisson, main.cu:189-200).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg1|NXxNYxNZ]
+
+N=1: cfg3 of BASELINE.json (512x512x512, four D3Q27 lattices + Poisson) when it fits the GPU,
+otherwise cfg2 (256^3, f+h+hn).  N>1 (launched by torch.distributed.run, one rank per GPU):
+weak scaling, every rank owns a 512x512x512 slab of a 512x512x(512 N) channel (cfg4 at N=2),
+z-slab decomposition with halo exchange over RCCL.
+
+One JSON line on rank 0.  `value` counts lattice-node updates of all ranks per wall second of
+the timed region (inputs resident in HBM, barrier + device sync on both sides, max over ranks).
+`roofline` is for the dominant kernel (the fused pull-stream/collide bulk kernel): algorithmic
+bytes per launch / its mean launch duration measured with HIP events on the kernel's stream.
+`cpu_baseline` is the CPU oracle (test infrastructure, never the measured product) timed on the
+host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def b_alg_lbm(nl: int) -> int:
+    """Algorithmic bytes per node of one bulk-kernel launch (LBM part):
+    every population read once and written once (nl*27*16), E read (24, nl>1), macroscopic
+    writes rho,u (32) + c,cn (16, nl>1) + T (8, nl>3)."""
+    return nl * 27 * 16 + (24 + 16 if nl > 1 else 0) + 32 + (8 if nl > 3 else 0)
+
+
+def b_alg_step(nl: int) -> int:
+    """Algorithmic bytes per node of the full step: LBM part + Poisson compulsory I/O 48
+    (read c,cn; write phi, E).  cfg3: 1856, cfg2: 1416, cfg1: 464 (no Poisson I/O credited)."""
+    return b_alg_lbm(nl) + (48 if nl > 1 else 0)
+
+
+def parse_workload(name: str, free_bytes: int):
+    if name == "auto":
+        need3 = 2 * 4 * 27 * 514 * 512 * 512 * 8 + 16 * 512**3 * 8
+        name = "cfg3" if free_bytes > need3 * 1.02 else "cfg2"
+    if name == "cfg3":
+        return name, (512, 512, 512), 4
+    if name == "cfg2":
+        return name, (256, 256, 256), 3
+    if name == "cfg1":
+        return name, (64, 64, 64), 1
+    nx, ny, nz = (int(v) for v in name.lower().split("x"))
+    return name, (nx, ny, nz), 4
+
+
+def apply_perturbation(sol, O, p):
+    """initialization() state + closed-form 3-D perturbation, plane by plane
+    to bound host memory."""
+    f = {k: sol.get_field(k) for k in ("rho", "c", "cn", "T")}
+    nz, ny, nx = sol.shape
+    z = (np.arange(nz) + sol.z0)[:, None, None]
+    y = np.arange(ny)[None, :, None]
+    x = np.arange(nx)[None, None, :]
+    X, Y, Z = 2 * np.pi * x / p.nx, 2 * np.pi * y / p.ny, np.pi * z / (p.nz - 1)
+    sZ = np.sin(Z)
+    sol.set_field("c", f["c"] * (1 + 0.02 * np.sin(X) * np.cos(2 * Y) * sZ))
+    sol.set_field("cn", f["cn"] * (1 + 0.02 * np.cos(2 * X) * np.sin(Y) * sZ))
+    sol.set_field("T", f["T"] + 0.05 * np.sin(X + Y) * sZ)
+    sol.set_field("rho", f["rho"] * (1 + 1e-6 * np.cos(X) * np.cos(Y) * sZ))
+    del f
+    sol.set_field("ux", 1e-4 * sZ * np.sin(X) * np.cos(Y))
+    sol.set_field("uy", -0.7e-4 * sZ * np.cos(X) * np.sin(2 * Y))
+    sol.set_field("uz", 0.5e-4 * sZ**2 * np.cos(X) * np.cos(Y))
+
+
+def cpu_baseline(nl: int, budget_s: float = 15.0):
+    """The CPU oracle (kind 'port': our restatement of the reference's step; the reference has
+    no CPU path) on all host cores, on a bounded sample of the same physics."""
+    O = G.load_oracle()
+    shape = (128, 128, 65)
+    p = O.default_params(*shape)
+    p.pb_iterations = 3
+    if nl < 4:
+        p.Ra = 0.0
+    o = O.Oracle(p)
+    o.initialization()
+    o.set_fields(O.perturb_fields(p, o.fields()))
+    o.fast_poisson()
+    o.init_equilibrium()
+    o.step(1)
+    t0 = time.perf_counter()
+    o.step(1)
+    per = time.perf_counter() - t0
+    k = max(2, min(200, int(budget_s / max(per, 1e-3))))
+    t0 = time.perf_counter()
+    o.step(k)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {
+        "value": round(o.n * k / dt / 1e6, 3),
+        "unit": "MLUPS",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{shape[0]}x{shape[1]}x{shape[2]} D3Q27 x4 lattices + Poisson, {k} steps, OpenMP oracle ({dt:.1f} s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="auto")
+    ap.add_argument("--ic", default="perturbed", choices=["perturbed", "uniform"])
+    ap.add_argument("--pb-iterations", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    pkg = G.load_package()
+    O = G.load_oracle() if False else None  # the oracle is only used by cpu_baseline()
+
+    free_b, total_b = torch.cuda.mem_get_info()
+    wname, (nx, ny, nz), nl = parse_workload(args.workload, free_b)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: WPS440
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        nz_global = nz * world  # weak scaling: one cfg-sized slab per GPU
+    else:
+        nz_global = nz
+
+    p = pkg.default_params(nx, ny, nz_global)
+    p.n_lattices = nl
+    if nl < 4:
+        p.Ra = 0.0
+    if nl == 1:
+        p.chargeinf, p.TH, p.exf = 0.0, 0.0, 1e9
+    if args.pb_iterations is not None:
+        p.pb_iterations = args.pb_iterations
+    elif nx * ny * nz > 64**3:
+        p.pb_iterations = 50  # untimed start-up (the reference's timer also starts after it, main.cu:161-186)
+
+    if world == 1:
+        sol = pkg.Solver(p)
+        runner = sol
+    else:
+        from ek_pnp_3d_amd.slab import DistributedSlab  # noqa: WPS433
+
+        runner = DistributedSlab(p, rank, world, dist)
+        sol = runner.solver
+
+    runner.initialization()
+    if args.ic == "perturbed":
+        apply_perturbation(sol, None, p)
+        runner.fast_Poisson()
+    runner.init_equilibrium()
+
+    def barrier():
+        sol.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    runner.step(args.warmup)
+    barrier()
+    sol.kernel_timing(True)
+    t0 = time.perf_counter()
+    runner.step(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    n_launch, k_ms, k_nodes = sol.kernel_timing_get()
+    sol.kernel_timing(False)
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    rho = sol.get_field("rho")
+    finite = bool(np.isfinite(rho).all())
+    nodes_total = nx * ny * nz_global
+    mlups = nodes_total * args.steps / dt / 1e6
+
+    if rank == 0:
+        launches_per_step = max(1, n_launch // max(1, args.steps))
+        k_avg_ms = k_ms / max(1, n_launch)
+        bytes_per_launch = b_alg_lbm(nl) * k_nodes
+        achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(wname, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MLUPS (full EK-PNP step)",
+            "value": round(mlups, 2),
+            "unit": "MLUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{wname}: {nx}x{ny}x{nz_global} D3Q27 x{nl} lattices"
+                + (" + spectral Poisson" if nl > 1 else "")
+                + (f", z-slabs of {nz} planes over {world} GPUs" if world > 1 else ""),
+                "grid": [nx, ny, nz_global],
+                "lattices": nl,
+                "ic": args.ic,
+                "b_alg_step_bytes_per_node": b_alg_step(nl),
+                "step_roofline_frac": round(b_alg_step(nl) * mlups / world * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
+                "device_bytes": sol.device_bytes(),
+                "finite": finite,
+            },
+            "roofline": {
+                "kernel": "k_collide_bulk",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "bytes_per_node": b_alg_lbm(nl),
+                "nodes_per_launch": int(k_nodes),
+                "launches_per_step": launches_per_step,
+                "avg_launch_ms": round(k_avg_ms, 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            runner.close()
+            out["cpu_baseline"] = cpu_baseline(nl)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

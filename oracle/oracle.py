@@ -76,6 +76,11 @@ def lib():
             getattr(L, fn).restype = None
         L.oracle_step.argtypes = [C.c_void_p, C.c_int]
         L.oracle_step.restype = None
+        L.oracle_set_dc_shift.argtypes = [C.c_void_p, C.c_double]
+        L.oracle_set_dc_shift.restype = None
+        for fn in ("oracle_initialization_shifts", "oracle_step_shifts"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+            getattr(L, fn).restype = None
         _lib = L
     return _lib
 
@@ -134,11 +139,22 @@ class Oracle:
     def stream_collide_save(self):
         lib().oracle_stream_collide_save(self._h)
 
-    def fast_poisson(self):
+    def fast_poisson(self, dc_shift: float = 0.0):
+        """dc_shift: measured interior shift of one reference solve (see oracle_set_dc_shift)."""
+        lib().oracle_set_dc_shift(self._h, float(dc_shift))
         lib().oracle_fast_poisson(self._h)
+        lib().oracle_set_dc_shift(self._h, 0.0)
 
     def step(self, n: int = 1):
         lib().oracle_step(self._h, n)
+
+    def step_shifts(self, shifts):
+        a = np.ascontiguousarray(shifts, dtype=np.float64)
+        lib().oracle_step_shifts(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size)
+
+    def initialization_shifts(self, shifts):
+        a = np.ascontiguousarray(shifts, dtype=np.float64)
+        lib().oracle_initialization_shifts(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size)
 
     # -- sub-kernels -----------------------------------------------------------------------
     def collide_save(self):

@@ -12,10 +12,18 @@
  * wavenumber tables), then calls the reference's host API exactly as main.cu:163-198 does and
  * dumps the 11 macroscopic fields as raw float64 (no lossy %10.6f ASCII, LBM.cu:2619).
  *
- * usage: ref_driver <outdir> init                       -> <outdir>/g1_init.bin, g1_step{1,5,20,100}.bin
- *        ref_driver <outdir> fields <in.bin> <tag> n... -> upload 11 fields, fast_Poisson,
- *                                                          init_equilibrium, dump after the listed steps
+ * usage: ref_driver <outdir> [--set name=value]... init <tag> n...
+ *            initialization() + init_equilibrium + steps; dumps <tag>_init.bin, <tag>_step<n>.bin,
+ *            <tag>_init_trace.bin ([sweeps][NZ] phi column after every PB sweep's fast_Poisson) and
+ *            <tag>_step_trace.bin ([steps][2][NZ] phi columns after every step)
+ *        ref_driver <outdir> [--set ...] fields <in.bin> <tag> n...
+ *            upload 11 fields, fast_Poisson, init_equilibrium, steps; dumps <tag>_step0.bin,
+ *            <tag>_step<n>.bin and <tag>_step_trace.bin ([1+steps][2][NZ])
  *        ref_driver <outdir> poisson <in.bin> <tag>     -> upload fields, one fast_Poisson, dump
+ *        --set name=value writes a __constant__/__device__ physics symbol of LBM.h at run time
+ *        (exf uw chargeinf voltage voltage2 Ext Ra TH): no source edit, hipMemcpyToSymbol only.
+ * The phi columns let the tests measure the reference's DC-mode leak (poisson.cu:177) of every
+ * single Poisson solve: phi_ref - phi_exact is one constant per solve on the interior.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,17 +62,90 @@ static void upload(const char* path) {
   fclose(f);
 }
 
+static std::vector<double> g_trace;
+static void trace_phi() { /* columns (0,0) and (NX/2,NY/2) of phi */
+  static std::vector<double> h((size_t)NX * NY * NZ);
+  CHECK(hipMemcpy(h.data(), phi_gpu, mem_size_scalar, hipMemcpyDeviceToHost));
+  for (unsigned z = 0; z < NZ; ++z) g_trace.push_back(h[scalar_index(0, 0, z)]);
+  for (unsigned z = 0; z < NZ; ++z) g_trace.push_back(h[scalar_index(NX / 2, NY / 2, z)]);
+}
+static void write_trace(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+  fwrite(g_trace.data(), sizeof(double), g_trace.size(), f);
+  fclose(f);
+  printf("wrote %s (%zu doubles)\n", path.c_str(), g_trace.size());
+  g_trace.clear();
+}
+
 static void one_step() { /* main.cu:189-200 */
   stream_collide_save(f0_gpu, f1_gpu, f2_gpu, h0_gpu, h1_gpu, h2_gpu, hn0_gpu, hn1_gpu, hn2_gpu, temp0_gpu, temp1_gpu, temp2_gpu,
                       rho_gpu, charge_gpu, chargen_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu, t, f0bc);
   fast_Poisson(charge_gpu, chargen_gpu, kx, ky, kz, plan);
   t = t + dt_host;
+  trace_phi();
+}
+
+/* The body of the reference's initialization() (LBM.cu:68-109), same kernels, same order, same
+ * host round trip of phi_old, with a phi trace after every fast_Poisson. */
+static void traced_initialization() {
+  dim3 grid(NX / nThreads, NY, NZ);
+  dim3 threads(nThreads, 1, 1);
+  gpu_initialization<<<grid, threads>>>(rho_gpu, charge_gpu, chargen_gpu, phi_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
+  checkCudaErrors(hipMalloc((void**)&phi_old_gpu, mem_size_scalar));
+  double* phi_old_host = (double*)malloc(mem_size_scalar);
+  CHECK(hipMemcpy(phi_old_host, phi_gpu, mem_size_scalar, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(phi_old_gpu, phi_old_host, mem_size_scalar, hipMemcpyHostToDevice));
+  for (unsigned int i = 0; i <= 500; ++i) {
+    gpu_PBE<<<grid, threads>>>(charge_gpu, phi_gpu, chargen_gpu);
+    fast_Poisson(charge_gpu, chargen_gpu, kx, ky, kz, plan);
+    trace_phi();
+    gpu_PBE_phi<<<grid, threads>>>(phi_gpu, phi_old_gpu);
+    CHECK(hipMemcpy(phi_old_host, phi_gpu, mem_size_scalar, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(phi_old_gpu, phi_old_host, mem_size_scalar, hipMemcpyHostToDevice));
+  }
+  free(phi_old_host);
+  checkCudaErrors(hipFree(phi_old_gpu));
+}
+
+static std::vector<double> snapshot() {
+  std::vector<double> all;
+  std::vector<double> h((size_t)NX * NY * NZ);
+  for (int i = 0; i < 11; ++i) {
+    CHECK(hipMemcpy(h.data(), g_fields[i], mem_size_scalar, hipMemcpyDeviceToHost));
+    all.insert(all.end(), h.begin(), h.end());
+  }
+  return all;
+}
+
+static void set_symbol(const std::string& kv) {
+  size_t eq = kv.find('=');
+  if (eq == std::string::npos) { fprintf(stderr, "bad --set %s\n", kv.c_str()); exit(2); }
+  std::string name = kv.substr(0, eq);
+  double v = atof(kv.c_str() + eq + 1);
+  hipError_t e = hipErrorInvalidValue;
+  if (name == "exf") e = hipMemcpyToSymbol(HIP_SYMBOL(exf), &v, sizeof(double));
+  else if (name == "uw") e = hipMemcpyToSymbol(HIP_SYMBOL(uw), &v, sizeof(double));
+  else if (name == "chargeinf") e = hipMemcpyToSymbol(HIP_SYMBOL(chargeinf), &v, sizeof(double));
+  else if (name == "voltage") e = hipMemcpyToSymbol(HIP_SYMBOL(voltage), &v, sizeof(double));
+  else if (name == "voltage2") e = hipMemcpyToSymbol(HIP_SYMBOL(voltage2), &v, sizeof(double));
+  else if (name == "Ext") e = hipMemcpyToSymbol(HIP_SYMBOL(Ext), &v, sizeof(double));
+  else if (name == "Ra") e = hipMemcpyToSymbol(HIP_SYMBOL(Ra), &v, sizeof(double));
+  else if (name == "TH") e = hipMemcpyToSymbol(HIP_SYMBOL(TH), &v, sizeof(double));
+  if (e != hipSuccess) { fprintf(stderr, "cannot set %s\n", name.c_str()); exit(2); }
+  printf("set %s = %.17g\n", name.c_str(), v);
 }
 
 int main(int argc, char** argv) {
   if (argc < 3) { fprintf(stderr, "usage: see header\n"); return 2; }
   std::string out = argv[1];
-  std::string mode = argv[2];
+  std::vector<std::string> sets, args;
+  for (int a = 2; a < argc; ++a) {
+    if (std::string(argv[a]) == "--set" && a + 1 < argc) sets.push_back(argv[++a]);
+    else args.push_back(argv[a]);
+  }
+  if (args.empty()) { fprintf(stderr, "usage: see header\n"); return 2; }
+  std::string mode = args[0];
 
   /* main.cu:21-35 */
   hipMemcpyFromSymbol(&dt_host, HIP_SYMBOL(dt), sizeof(double), 0, hipMemcpyDeviceToHost);
@@ -79,6 +160,7 @@ int main(int argc, char** argv) {
   hipMemcpyToSymbol(HIP_SYMBOL(K), &K_host, sizeof(double), 0, hipMemcpyHostToDevice);
   hipMemcpyToSymbol(HIP_SYMBOL(Kn), &Kn_host, sizeof(double), 0, hipMemcpyHostToDevice);
   hipMemcpyToSymbol(HIP_SYMBOL(epsn), &epsn_host, sizeof(double), 0, hipMemcpyHostToDevice);
+  for (auto& kv : sets) set_symbol(kv);
 
   checkCudaErrors(hipSetDevice(0));
   /* main.cu:78-109 */
@@ -119,37 +201,48 @@ int main(int argc, char** argv) {
 
   printf("reference grid %ux%ux%u (NE=%u) dt=%g\n", NX, NY, NZ, NE, dt_host);
 
-  if (mode == "init") {
-    /* main.cu:169-175 */
+  if (mode == "init" && args.size() >= 2) {
+    std::string tag = args[1];
+    /* main.cu:169-175: the reference's own initialization() first ... */
     initialization(rho_gpu, charge_gpu, chargen_gpu, phi_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
+    std::vector<double> a = snapshot();
+    /* ... then its body again with the phi trace; both must agree bit for bit */
+    traced_initialization();
+    std::vector<double> b = snapshot();
+    printf("traced initialization bitwise identical to initialization(): %s\n",
+           memcmp(a.data(), b.data(), a.size() * sizeof(double)) == 0 ? "yes" : "NO");
+    write_trace(out + "/" + tag + "_init_trace.bin");
     t = 0;
-    dump(out + "/g1_init.bin");
+    dump(out + "/" + tag + "_init.bin");
     init_equilibrium(f0_gpu, f1_gpu, h0_gpu, h1_gpu, hn0_gpu, hn1_gpu, temp0_gpu, temp1_gpu, rho_gpu, charge_gpu, chargen_gpu, ux_gpu,
                      uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
-    const int marks[4] = {1, 5, 20, 100};
     int done = 0;
-    for (int m = 0; m < 4; ++m) {
-      for (; done < marks[m]; ++done) one_step();
-      dump(out + "/g1_step" + std::to_string(marks[m]) + ".bin");
+    for (size_t a2 = 2; a2 < args.size(); ++a2) {
+      int mark = atoi(args[a2].c_str());
+      for (; done < mark; ++done) one_step();
+      dump(out + "/" + tag + "_step" + std::to_string(mark) + ".bin");
     }
-  } else if (mode == "fields" && argc >= 6) {
-    upload(argv[3]);
-    std::string tag = argv[4];
+    write_trace(out + "/" + tag + "_step_trace.bin");
+  } else if (mode == "fields" && args.size() >= 3) {
+    upload(args[1].c_str());
+    std::string tag = args[2];
     fast_Poisson(charge_gpu, chargen_gpu, kx, ky, kz, plan);
+    trace_phi();
     dump(out + "/" + tag + "_step0.bin");
     init_equilibrium(f0_gpu, f1_gpu, h0_gpu, h1_gpu, hn0_gpu, hn1_gpu, temp0_gpu, temp1_gpu, rho_gpu, charge_gpu, chargen_gpu, ux_gpu,
                      uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
     t = 0;
     int done = 0;
-    for (int a = 5; a < argc; ++a) {
-      int mark = atoi(argv[a]);
+    for (size_t a2 = 3; a2 < args.size(); ++a2) {
+      int mark = atoi(args[a2].c_str());
       for (; done < mark; ++done) one_step();
       dump(out + "/" + tag + "_step" + std::to_string(mark) + ".bin");
     }
-  } else if (mode == "poisson" && argc >= 5) {
-    upload(argv[3]);
+    write_trace(out + "/" + tag + "_step_trace.bin");
+  } else if (mode == "poisson" && args.size() >= 3) {
+    upload(args[1].c_str());
     fast_Poisson(charge_gpu, chargen_gpu, kx, ky, kz, plan);
-    dump(out + "/" + std::string(argv[4]) + ".bin");
+    dump(out + "/" + args[2] + ".bin");
   } else {
     fprintf(stderr, "bad mode\n");
     return 2;

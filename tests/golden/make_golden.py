@@ -54,19 +54,22 @@ def main(outdir):
     p = O.default_params(NX, NY, NZ)
     p.Lx, p.Ly, p.Lz = 0.5e-6, 0.08e-6, 0.5e-6
 
-    # ---- G1
-    run("init")
+    def trace(path, n):
+        a = np.fromfile(path, dtype=np.float64)
+        return a.reshape(n, 2, NZ)
+
+    # ---- G1: default run, x-y uniform
+    run("init", "g1", "1", "5", "20", "100")
     g1 = {"marks": np.array([1, 5, 20, 100])}
     init = read_bin(os.path.join(tmp, "g1_init.bin"))
-    xy_dev = {}
     for tag, f in [("init", init)] + [(f"step{m}", read_bin(os.path.join(tmp, f"g1_step{m}.bin"))) for m in (1, 5, 20, 100)]:
         for k, v in f.items():
             g1[f"{tag}_{k}"] = v
-            xy_dev[f"{tag}_{k}"] = float(np.abs(v - v[:, :1, :1]).max())
+    g1["init_trace"] = trace(os.path.join(tmp, "g1_init_trace.bin"), 501)
+    g1["step_trace"] = trace(os.path.join(tmp, "g1_step_trace.bin"), 100)
     np.savez_compressed(os.path.join(outdir, "ref_g1_full.npz"), **g1)
-    print("G1 max x-y non-uniformity:", max(xy_dev.values()))
 
-    # ---- G2
+    # ---- G2: perturbed 3-D run
     start = O.perturb_fields(p, init)
     inp = os.path.join(tmp, "g2_in.bin")
     write_bin(inp, start)
@@ -78,7 +81,18 @@ def main(outdir):
         f = read_bin(os.path.join(tmp, f"g2_step{m}.bin"))
         for k, v in f.items():
             g2[f"step{m}_{k}"] = v
+    g2["step_trace"] = trace(os.path.join(tmp, "g2_step_trace.bin"), 51)
     np.savez_compressed(os.path.join(outdir, "ref_g2_full.npz"), **g2)
+
+    # ---- G3: body-force driven channel (Poiseuille), no ions, no buoyancy: rho and u do not
+    # depend on phi at all here (force = F (c - cn) E = 0), so they are free of the DC leak.
+    run("--set", "exf=1e9", "--set", "chargeinf=0", "--set", "Ra=0", "--set", "TH=0", "init", "g3", "1", "100", "3000")
+    g3 = {"marks": np.array([1, 100, 3000])}
+    for m in (1, 100, 3000):
+        f = read_bin(os.path.join(tmp, f"g3_step{m}.bin"))
+        for k in ("rho", "ux", "uy", "uz", "c", "cn", "T"):
+            g3[f"step{m}_{k}"] = f[k]
+    np.savez_compressed(os.path.join(outdir, "ref_g3_full.npz"), **g3)
 
     # ---- G5
     rng = np.random.default_rng(5)

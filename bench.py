@@ -101,7 +101,7 @@ def cpu_baseline(nl: int, budget_s: float = 15.0):
     t0 = time.perf_counter()
     o.step(k)
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cores = o.threads
     return {
         "value": round(o.n * k / dt / 1e6, 3),
         "unit": "MLUPS",

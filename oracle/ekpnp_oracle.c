@@ -34,7 +34,28 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define Q 27
+
+/* Worker threads of the OpenMP loops.  The GPU box exposes every hardware thread of the host
+ * but grants ~16 cores: an unbounded team oversubscribes and crawls, so the front-end sets it. */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n < 1 ? 1 : n);
+#else
+  (void)n;
+#endif
+}
+int oracle_get_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 
 /* D3Q27 velocity set, recovered from the stream offsets of gpu_stream
  * (LBM.cu:1983-2008): f1[d](x) = f2[d](x - c_d).  Opposite of odd d is d+1. */

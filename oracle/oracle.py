@@ -81,8 +81,28 @@ def lib():
         for fn in ("oracle_initialization_shifts", "oracle_step_shifts"):
             getattr(L, fn).argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
             getattr(L, fn).restype = None
+        L.oracle_set_num_threads.argtypes = [C.c_int]
+        L.oracle_set_num_threads.restype = None
+        L.oracle_get_max_threads.restype = C.c_int
         _lib = L
     return _lib
+
+
+def host_cores() -> int:
+    """Cores the oracle may use: OMP_NUM_THREADS if set, else min(16, affinity) - the GPU box
+    grants about 16 cores per GPU while exposing every hardware thread of the host."""
+    if os.environ.get("OMP_NUM_THREADS"):
+        return max(1, int(os.environ["OMP_NUM_THREADS"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def set_threads(n: int) -> int:
+    lib().oracle_set_num_threads(int(n))
+    return lib().oracle_get_max_threads()
 
 
 def default_params(nx: int, ny: int, nz: int) -> Params:
@@ -99,6 +119,8 @@ class Oracle:
         self._h = lib().oracle_create(C.byref(self.p), dc_mode)
         self.shape = (self.p.nz, self.p.ny, self.p.nx)
         self.n = self.p.nx * self.p.ny * self.p.nz
+        # small lattices: a thread team costs more than it saves
+        self.threads = set_threads(1 if self.n < 100_000 else host_cores())
 
     def close(self):
         if self._h:

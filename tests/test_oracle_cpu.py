@@ -144,54 +144,108 @@ def test_subkernels_compose_to_stream_collide_save(O):
             assert np.array_equal(a.population(lat, w), b.population(lat, w))
 
 
-# ---- golden vectors from the reference's own kernels (made on the GPU box) ----------------
+# ---- golden vectors from the reference's own kernels (made on an MI355X) --------------------
+# tests/golden/ref_g*.npz hold outputs of the reference's LBM.cu / poisson.cu kernels built for
+# gfx950 (oracle/build_ref.sh -> make_golden.py -> pack_golden.py).  The reference's Poisson
+# solve leaks its FFT library's rounding residue into the DC mode (poisson.cu:177): one constant
+# per solve on the interior phi, up to 4e-4 on a 5e-3 field.  The fixtures carry the measured
+# constant of every solve (`*_shifts`); replaying the run with them injected must reproduce the
+# reference to FP64 rounding.  TOL_U: see tests/test_parity_gpu.py.
+TOL, TOL_U = 1e-12, 1e-7
+
 
 def _need(name):
     path = golden_path(name)
     if not os.path.exists(path):
-        pytest.skip(f"{name} not generated yet (tests/golden/make_golden.py on the GPU box)")
+        pytest.skip(f"{name} missing (tests/golden/make_golden.py on the GPU box, then pack_golden.py)")
     return np.load(path)
 
 
-def test_golden_G1_default_run(O):
+def _check(err, where):
+    bad = {k: v for k, v in err.items() if not v <= (TOL_U if k == "u" else TOL)}
+    assert not bad, (where, err)
+
+
+def test_golden_G1_default_run_init_and_100_steps(O):
+    """The reference's own default run: initialization() with all 501 PB sweeps, then 100 steps."""
     g = _need("ref_g1.npz")
     p = _ref_grid(O)
     o = O.Oracle(p)
-    o.initialization()
-    got = o.fields()
-    want = {k: g["init_" + k] for k in O.FIELDS}
-    err = O.rel_l2({k: got[k] for k in ("phi", "c", "cn", "Ex", "Ey", "Ez", "T", "rho")},
-                   want, {k: v for k, v in O.GROUPS.items() if k != "u"})
-    assert max(err.values()) < float(g["tol_init"]), err
+    o.initialization_shifts(g["init_shifts"])
+    f = o.fields()
+    for k, v in f.items():
+        if k in ("Ex", "Ey", "ux", "uy", "uz"):
+            continue  # zero up to the rounding noise of the oracle's DFT (1e-10 V/m next to Ez = 5e4)
+        # the reference's fields are bit-exactly x-y uniform; the oracle's DFT leaves rounding noise
+        assert np.abs(v - v[:, :1, :1]).max() <= 1e-12 * (np.abs(v).max() + 1e-300), f"{k} must stay x-y uniform"
+    col = lambda d: {k: v[:, 0, 0] for k, v in d.items()}  # noqa: E731
+    groups = {k: v for k, v in O.GROUPS.items() if k != "u"}  # u == 0 exactly after initialization
+    _check(O.rel_l2(col(f), {k: g["init_" + k] for k in O.FIELDS}, groups), "init")
+    assert not np.any(f["ux"]) and not np.any(g["init_ux"])
     o.init_equilibrium()
     done = 0
     for mark in (int(m) for m in g["marks"]):
-        o.step(mark - done)
+        o.step_shifts(g["step_shifts"][done:mark])
         done = mark
-        err = O.rel_l2(o.fields(), {k: g[f"step{mark}_{k}"] for k in O.FIELDS})
-        assert max(err.values()) < float(g["tol_steps"]), (mark, err)
+        _check(O.rel_l2(col(o.fields()), {k: g[f"step{mark}_{k}"] for k in O.FIELDS}), f"step {mark}")
 
 
-def test_golden_G2_perturbed_run(O):
+def test_golden_G1_dc_leak_is_what_separates_exact_from_reference(O):
+    """Without the measured shifts the exact solve differs from the reference's run by the leak
+    (this documents why 'DC = 0' is the canonical result)."""
+    g = _need("ref_g1.npz")
+    assert np.abs(g["init_shifts"]).max() > 1e-4  # 4e-4 on a 5.3e-3 potential
+    residues = -g["init_shifts"] * (50 * 8 * 100)  # shift = -residue / size, LBM.h:38
+    assert np.abs(residues - np.round(residues * 128) / 128).max() < 1e-6  # multiples of ulp(5e13) = 2^-7
+
+
+def test_golden_G2_perturbed_3d_run(O):
     g = _need("ref_g2.npz")
     p = _ref_grid(O)
+    ys = list(g["ysel"])
     o = O.Oracle(p)
-    o.set_fields({k: g["input_" + k] for k in O.FIELDS})
-    o.fast_poisson()
+    o.gpu_initialization()
+    o.set_fields({k: g["input_" + k] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+    sub = lambda d: {k: v[:, ys, :] for k, v in d.items()}  # noqa: E731
+    o.fast_poisson(float(g["shifts"][0]))
+    _check(O.rel_l2(sub(o.fields()), {k: g["step0_" + k] for k in O.FIELDS}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]}), "step 0")
     o.init_equilibrium()
     done = 0
     for mark in (int(m) for m in g["marks"]):
+        o.step_shifts(g["shifts"][1 + done : 1 + mark])
+        done = mark
+        _check(O.rel_l2(sub(o.fields()), {k: g[f"step{mark}_{k}"] for k in O.FIELDS}), f"step {mark}")
+
+
+def test_golden_G3_body_force_channel(O):
+    """exf = 1e9, chargeinf = 0, Ra = 0, TH = 0: rho and u do not see phi, no shift involved."""
+    g = _need("ref_g3.npz")
+    p = _ref_grid(O)
+    p.exf, p.chargeinf, p.Ra, p.TH = 1e9, 0.0, 0.0, 0.0
+    o = O.Oracle(p)
+    o.initialization()
+    o.init_equilibrium()
+    done = 0
+    full = os.environ.get("EKPNP_LONG_TESTS") == "1"  # the 3000-step mark takes minutes on one core
+    for mark in (int(m) for m in g["marks"] if full or m <= 100):
         o.step(mark - done)
         done = mark
-        err = O.rel_l2(o.fields(), {k: g[f"step{mark}_{k}"] for k in O.FIELDS})
-        assert max(err.values()) < float(g["tol_steps"]), (mark, err)
+        f = {k: o.field(k)[:, [0, 3, 5], :] for k in ("rho", "ux", "uy", "uz")}
+        err = O.rel_l2(f, {k: g[f"step{mark}_{k}"] for k in f}, {"rho": ["rho"], "u": ["ux", "uy", "uz"]})
+        assert err["rho"] < 1e-12 and err["u"] < 1e-9, (mark, err)
 
 
 def test_golden_G5_poisson_alone(O):
     g = _need("ref_g5.npz")
     p = _ref_grid(O)
+    ys = list(g["ysel"])
     o = O.Oracle(p)
-    o.set_fields({k: g["input_" + k] for k in O.FIELDS})
-    o.fast_poisson()
-    err = O.rel_l2(o.fields(), {k: g["out_" + k] for k in ("phi", "Ex", "Ey", "Ez")}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
-    assert max(err.values()) < float(g["tol"]), err
+    o.gpu_initialization()
+    o.set_fields({"c": g["input_c"], "cn": g["input_cn"]})
+    o.fast_poisson(float(g["shift"]))
+    got = {k: o.field(k)[:, ys, :] for k in ("phi", "Ex", "Ey", "Ez")}
+    _check(O.rel_l2(got, {k: g["out_" + k] for k in got}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]}), "poisson")
+    # and the exact solve differs from the reference by exactly that constant on the interior
+    o.fast_poisson(0.0)
+    d = g["out_phi"][1:-1] - o.field("phi")[1:-1][:, ys, :]
+    assert np.abs(d - float(g["shift"])).max() < 1e-16

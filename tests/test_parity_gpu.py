@@ -220,45 +220,67 @@ def test_mass_conservation_and_symmetry_at_scale(pkg, O):
         assert np.abs(f[k] - prof).max() <= 1e-9 * scale, k
 
 
-# ---- golden vectors produced by the reference's own kernels ------------------------------
+# ---- golden vectors produced by the reference's own kernels --------------------------------
+# The HIP path returns the exact (DC = 0) Poisson solution, the reference's run carries its FFT
+# library's DC-mode leak (tests/test_oracle_cpu.py pins the oracle to the reference WITH the
+# measured leak injected).  Directly comparable are the quantities that do not see phi.
 
 def _need(name):
     path = golden_path(name)
     if not os.path.exists(path):
-        pytest.skip(f"{name} not generated yet")
+        pytest.skip(f"{name} missing")
     return np.load(path)
 
 
-def test_golden_G2_hip_vs_reference_kernels(pkg, O):
-    g = _need("ref_g2.npz")
+def _ref_grid(O):
     po = O.default_params(50, 8, 51)
     po.Lx, po.Ly, po.Lz = 0.5e-6, 0.08e-6, 0.5e-6
-    with pkg.Solver(_mirror(pkg, po)) as s:
-        s.set_fields({k: g["input_" + k] for k in O.FIELDS})
-        s.fast_Poisson()
-        s.init_equilibrium()
-        done = 0
-        for mark in (int(m) for m in g["marks"]):
-            s.step(mark - done)
-            done = mark
-            err = O.rel_l2(s.fields(), {k: g[f"step{mark}_{k}"] for k in O.FIELDS})
-            assert max(err.values()) < float(g["tol_steps"]), (mark, err)
+    return po
 
 
-def test_golden_G1_hip_vs_reference_kernels(pkg, O):
-    g = _need("ref_g1.npz")
-    po = O.default_params(50, 8, 51)
-    po.Lx, po.Ly, po.Lz = 0.5e-6, 0.08e-6, 0.5e-6
+def test_golden_G3_hip_vs_reference_kernels_direct(pkg, O):
+    g = _need("ref_g3.npz")
+    po = _ref_grid(O)
+    po.exf, po.chargeinf, po.Ra, po.TH = 1e9, 0.0, 0.0, 0.0
     with pkg.Solver(_mirror(pkg, po)) as s:
         s.initialization()
-        got = s.fields()
-        want = {k: g["init_" + k] for k in O.FIELDS}
-        err = O.rel_l2(got, want, {k: v for k, v in O.GROUPS.items() if k != "u"})
-        assert max(err.values()) < float(g["tol_init"]), err
         s.init_equilibrium()
         done = 0
         for mark in (int(m) for m in g["marks"]):
             s.step(mark - done)
             done = mark
-            err = O.rel_l2(s.fields(), {k: g[f"step{mark}_{k}"] for k in O.FIELDS})
-            assert max(err.values()) < float(g["tol_steps"]), (mark, err)
+            f = {k: s.get_field(k)[:, [0, 3, 5], :] for k in ("rho", "ux", "uy", "uz")}
+            err = O.rel_l2(f, {k: g[f"step{mark}_{k}"] for k in f}, {"rho": ["rho"], "u": ["ux", "uy", "uz"]})
+            _REPORT.append({"test": "golden_G3_direct", "mark": str(mark), "rel_l2": err})
+            assert err["rho"] < 1e-12 and err["u"] < 1e-8, (mark, err)
+
+
+def test_golden_G5_hip_poisson_vs_reference_modulo_dc_leak(pkg, O):
+    """HIP phi == reference phi minus the reference's measured DC constant, to rounding."""
+    g = _need("ref_g5.npz")
+    po = _ref_grid(O)
+    ys = list(g["ysel"])
+    with pkg.Solver(_mirror(pkg, po)) as s:
+        s.set_field("c", g["input_c"])
+        s.set_field("cn", g["input_cn"])
+        s.fast_Poisson()
+        phi = s.get_field("phi")[:, ys, :]
+    d = g["out_phi"][1:-1] - phi[1:-1]
+    assert np.abs(d - float(g["shift"])).max() < 1e-15
+    assert np.array_equal(phi[0], g["out_phi"][0]) and np.array_equal(phi[-1], g["out_phi"][-1])
+
+
+def test_golden_G2_hip_first_step_moments_vs_reference(pkg, O):
+    """c, cn, rho, T written by the first collide (LBM.cu:807-813) do not depend on phi."""
+    g = _need("ref_g2.npz")
+    po = _ref_grid(O)
+    ys = list(g["ysel"])
+    with pkg.Solver(_mirror(pkg, po)) as s:
+        s.set_fields({k: g["input_" + k] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+        s.fast_Poisson()
+        s.init_equilibrium()
+        s.step(1)
+        f = {k: s.get_field(k)[:, ys, :] for k in ("rho", "c", "cn", "T")}
+    err = O.rel_l2(f, {k: g["step1_" + k] for k in f}, {k: [k] for k in f})
+    _REPORT.append({"test": "golden_G2_step1_moments", "mark": "1", "rel_l2": err})
+    assert max(err.values()) < 1e-13, err

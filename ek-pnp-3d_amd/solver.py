@@ -75,6 +75,12 @@ def load_library():
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    try:
+        # PyTorch-ROCm is the plumbing for device memory / streams / torch.distributed.  It ships
+        # its own HIP runtime + rocFFT; load it first so that one runtime serves the process.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     ctx = C.c_void_p
     i32, dbl, sz = C.c_int, C.c_double, C.c_size_t

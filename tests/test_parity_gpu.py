@@ -204,16 +204,18 @@ def test_bind_field_uses_caller_memory(pkg, O):
 
 def test_mass_conservation_and_symmetry_at_scale(pkg, O):
     """Size-independent properties on a grid the oracle would take minutes for (256x64x66):
-    total fluid mass of the interior is conserved, an x-y uniform start stays x-y uniform."""
+    total fluid mass (all nodes, walls included) is conserved, an x-y uniform start stays x-y
+    uniform."""
     p = pkg.default_params(256, 64, 66)
     p.pb_iterations = 30
     with pkg.Solver(p) as s:
         s.initialization(); s.init_equilibrium()
         s.step(1)
-        m0 = s.get_field("rho")[1:-1].sum()
+        m0 = s.get_field("rho").sum()
         s.step(40)
         f = s.fields()
-    assert abs(f["rho"][1:-1].sum() / m0 - 1) < 1e-12
+    assert all(np.isfinite(v).all() for v in f.values())
+    assert abs(f["rho"].sum() / m0 - 1) < 1e-12
     for k in ("rho", "c", "cn", "phi", "T", "Ez", "uz"):
         prof = f[k][:, :1, :1]
         scale = np.abs(f[k]).max() + 1e-300

@@ -1,0 +1,46 @@
+"""Condenses gpurun_out/prof_<tag>/ (tools/profile.sh) into profiles/<tag>_*: the kernel-stats
+CSV, a PMC summary with the gfx950 FETCH_SIZE correction calibrated on tools/pmc_calib, and
+profiles/pmc_traffic.json (HBM bytes per launch of the dominant kernel, read by bench.py)."""
+import collections, csv, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+wl = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"))
+
+def agg(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in d.items()}
+
+cf, cw = agg(os.path.join(src, "calib_fetch", "pmc_counter_collection.csv")), agg(os.path.join(src, "calib_write", "pmc_counter_collection.csv"))
+copy_name = next(k for k in cf if k.startswith("k_copy8("))
+shift_name = next(k for k in cf if k.startswith("k_copy8_shift("))
+true_kib = (1 << 30) * 8 / 1024
+fetch_factor = true_kib / cf[copy_name]          # 2.0 on gfx950: FETCH_SIZE tallies 128-B requests at 64 B
+write_factor = true_kib / cw[copy_name]
+pf, pw = agg(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv")), agg(os.path.join(src, "pmc_write", "pmc_counter_collection.csv"))
+out = {"calibration": {"kernel": "tools/pmc_calib k_copy8 (8 B/lane, 8 GiB read + 8 GiB write)",
+                       "FETCH_SIZE_KiB": cf[copy_name], "WRITE_SIZE_KiB": cw[copy_name], "true_KiB": true_kib,
+                       "fetch_factor": fetch_factor, "write_factor": write_factor,
+                       "misaligned_by_one_element_fetch_ratio": cf[shift_name] / cf[copy_name]},
+       "kernels": {}}
+for k in sorted(set(pf) | set(pw)):
+    f, w = pf.get(k, 0.0), pw.get(k, 0.0)
+    out["kernels"][k] = {"FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w,
+                         "hbm_read_bytes": f * 1024 * fetch_factor, "hbm_write_bytes": w * 1024 * write_factor,
+                         "hbm_bytes_per_launch": f * 1024 * fetch_factor + w * 1024 * write_factor}
+json.dump(out, open(os.path.join(dst, f"{tag}_{wl}_pmc_summary.json"), "w"), indent=1)
+bulk = next(k for k in out["kernels"] if "k_collide_bulk" in k and "true" in k)
+tpath = os.path.join(dst, "pmc_traffic.json")
+t = json.load(open(tpath)) if os.path.exists(tpath) else {}
+t[wl] = {"kernel": bulk, "hbm_bytes_per_launch": out["kernels"][bulk]["hbm_bytes_per_launch"], "round": tag,
+         "note": "(FETCH_SIZE*fetch_factor + WRITE_SIZE)*1024, separate --pmc passes, calibrated on tools/pmc_calib"}
+json.dump(t, open(tpath, "w"), indent=1)
+for f in ("calib_fetch.log",):
+    shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_pmc_calib.log"))
+print(json.dumps(out["calibration"], indent=1)); print(bulk, out["kernels"][bulk])

@@ -187,13 +187,27 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   }
   if ((rc = dev_alloc(c, (void**)&c.work, c.nloc * sizeof(double)))) return bail(rc);
   if ((rc = dev_alloc(c, (void**)&c.spec, (size_t)c.nzl * p->ny * c.nxh * sizeof(double2)))) return bail(rc);
-  if ((rc = dev_alloc(c, (void**)&c.cprime, (size_t)p->nz * p->ny * c.nxh * sizeof(double)))) return bail(rc);
+  const size_t nmodes = (size_t)p->ny * c.nxh;
+  const size_t cprime_rows = nranks == 1 ? (size_t)p->nz : (size_t)c.nzl + 2;
+  if ((rc = dev_alloc(c, (void**)&c.cprime, cprime_rows * nmodes * sizeof(double)))) return bail(rc);
   c.halo_doubles = (size_t)p->n_lattices * 9 * c.plane;
   if (nranks > 1) {
+    if (nranks > 16) { c.err = "at most 16 z slabs"; return bail(EKPNP_ERR_INVALID); }
     for (int k = 0; k < 4; ++k) {
       if ((rc = dev_alloc(c, (void**)&c.halo[k], c.halo_doubles * sizeof(double)))) return bail(rc);
       if ((rc = dev_alloc(c, (void**)&c.phi_halo[k], c.plane * sizeof(double)))) return bail(rc);
+      if (hipMemsetAsync(c.halo[k], 0, c.halo_doubles * sizeof(double), c.stream) != hipSuccess ||
+          hipMemsetAsync(c.phi_halo[k], 0, c.plane * sizeof(double), c.stream) != hipSuccess) { c.err = "hipMemsetAsync failed"; return bail(EKPNP_ERR_HIP); }
     }
+    // unknown rows of the global z system owned by this slab: interior planes only
+    c.slab_row_a = (c.z0 == 0) ? 1 : 0;
+    const int row_e = (c.z0 + c.nzl == p->nz) ? c.nzl - 2 : c.nzl - 1;
+    c.slab_m = row_e - c.slab_row_a + 1;
+    if ((rc = dev_alloc(c, (void**)&c.slab_u, (size_t)c.slab_m * nmodes * sizeof(double)))) return bail(rc);
+    for (int k = 0; k < 2; ++k)
+      if ((rc = dev_alloc(c, (void**)&c.u1um[k], 2 * nmodes * sizeof(double)))) return bail(rc);
+    if ((rc = dev_alloc(c, (void**)&c.edge_local, 4 * nmodes * sizeof(double)))) return bail(rc);
+    if ((rc = dev_alloc(c, (void**)&c.edge_all, (size_t)nranks * 4 * nmodes * sizeof(double)))) return bail(rc);
   }
   // batched 2-D real transforms over the owned planes (replaces cufftPlan3d, main.cu:112)
   {
@@ -206,6 +220,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
     hipfftSetStream(c.plan_inv, c.stream);
   }
   build_cprime(c);
+  if (!c.err.empty()) return bail(EKPNP_ERR_NOMEM);
   if (hipStreamSynchronize(c.stream) != hipSuccess || hipGetLastError() != hipSuccess) { c.err = "device initialisation failed"; return bail(EKPNP_ERR_HIP); }
   *out = h;
   return EKPNP_OK;
@@ -226,6 +241,12 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (c.work) (void)hipFree(c.work);
   if (c.spec) (void)hipFree(c.spec);
   if (c.cprime) (void)hipFree(c.cprime);
+  if (c.slab_u) (void)hipFree(c.slab_u);
+  if (c.u1um[0]) (void)hipFree(c.u1um[0]);
+  if (c.u1um[1]) (void)hipFree(c.u1um[1]);
+  if (c.edge_local) (void)hipFree(c.edge_local);
+  if (c.edge_all) (void)hipFree(c.edge_all);
+  if (c.phi_old) (void)hipFree(c.phi_old);
   for (int k = 0; k < 4; ++k) {
     if (c.halo[k]) (void)hipFree(c.halo[k]);
     if (c.phi_halo[k]) (void)hipFree(c.phi_halo[k]);
@@ -333,23 +354,54 @@ extern "C" int ekpnp_fast_poisson(ekpnp_ctx* ctx) {
 // ------------------------------------------------------------------------------------------
 // initial state
 
+extern "C" int ekpnp_init_fields(ekpnp_ctx* ctx) {  // gpu_initialization, LBM.cu:111-128
+  NEEDCTX(ctx);
+  launch_init_fields(c);
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_pbe_begin(ekpnp_ctx* ctx) {  // LBM.cu:79-86: phi_old <- phi
+  NEEDCTX(ctx);
+  if (!c.phi_old) HIPCHK(c, hipMalloc((void**)&c.phi_old, c.nloc * sizeof(double)));
+  HIPCHK(c, hipMemcpyAsync(c.phi_old, c.fld[EKPNP_PHI], c.nloc * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_pbe_concentrations(ekpnp_ctx* ctx) {  // gpu_PBE, LBM.cu:139-146
+  NEEDCTX(ctx);
+  launch_pbe(c);
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_pbe_relax(ekpnp_ctx* ctx) {  // gpu_PBE_phi + phi_old update, LBM.cu:98-104
+  NEEDCTX(ctx);
+  if (!c.phi_old) return fail(c, "ekpnp_pbe_relax without ekpnp_pbe_begin");
+  launch_pbe_relax(c, c.phi_old);
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_pbe_end(ekpnp_ctx* ctx) {  // LBM.cu:107-108
+  NEEDCTX(ctx);
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  if (c.phi_old) { (void)hipFree(c.phi_old); c.phi_old = nullptr; }
+  return EKPNP_OK;
+}
+
 extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks != 1) return fail(c, "ekpnp_initialization on a slab context: drive the PB sweeps through the slab host (Poisson needs the transport)");
-  launch_init_fields(c);
-  double* phi_old = nullptr;
-  HIPCHK(c, hipMalloc((void**)&phi_old, c.nloc * sizeof(double)));
-  // LBM.cu:82-86: phi_old <- phi
-  hipError_t e = hipMemcpyAsync(phi_old, c.fld[EKPNP_PHI], c.nloc * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
-  int rc = EKPNP_OK;
-  if (e != hipSuccess) { c.err = "hipMemcpyAsync failed"; rc = EKPNP_ERR_HIP; }
+  if (c.nranks != 1) return fail(c, "ekpnp_initialization on a slab context: drive ekpnp_init_fields / ekpnp_pbe_* and the Poisson stages through the slab host");
+  int rc = ekpnp_init_fields(ctx);
+  if (rc == EKPNP_OK) rc = ekpnp_pbe_begin(ctx);
   for (int i = 0; rc == EKPNP_OK && i < c.p.pb_iterations; ++i) {  // LBM.cu:89-106
     launch_pbe(c);
     rc = poisson_single(c);
-    launch_pbe_relax(c, phi_old);
+    launch_pbe_relax(c, c.phi_old);
   }
-  (void)hipStreamSynchronize(c.stream);
-  (void)hipFree(phi_old);
+  int rc2 = ekpnp_pbe_end(ctx);
+  if (rc == EKPNP_OK) rc = rc2;
   if (rc == EKPNP_OK) HIPCHK(c, hipGetLastError());
   return rc;
 }
@@ -457,7 +509,7 @@ extern "C" int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* 
 }
 
 // ------------------------------------------------------------------------------------------
-// z-slab interface (filled in by slab.hip once the distributed tridiagonal lands)
+// z-slab interface; the transport between the calls is the caller's
 
 extern "C" int ekpnp_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, size_t* n) {
   NEEDCTX(ctx);
@@ -480,7 +532,8 @@ extern "C" int ekpnp_phi_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, s
 extern "C" int ekpnp_halo_pack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
-  launch_halo_pack(c);
+  // between the boundary and the interior call the fresh planes are in the NEXT buffer
+  launch_halo_pack(c, c.collide_phase == 1 ? (c.cur ^ 1) : c.cur);
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;
 }
@@ -488,16 +541,81 @@ extern "C" int ekpnp_halo_pack(ekpnp_ctx* ctx) {
 extern "C" int ekpnp_halo_unpack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  if (c.collide_phase != 0) return fail(c, "ekpnp_halo_unpack before ekpnp_collide_interior_planes");
   launch_halo_unpack(c);
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;
 }
 
-static int not_yet(Ctx& c) { return fail(c, "z-slab Poisson stages are not implemented in this build"); }
-extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
-extern "C" int ekpnp_poisson_edge_buffer(ekpnp_ctx* ctx, int, double**, size_t*) { NEEDCTX(ctx); return not_yet(c); }
-extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
-extern "C" int ekpnp_phi_halo_pack(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
-extern "C" int ekpnp_poisson_stage3(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
-extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
-extern "C" int ekpnp_collide_interior_planes(ekpnp_ctx* ctx) { NEEDCTX(ctx); return not_yet(c); }
+extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_stream_collide_save");
+  if (c.collide_phase != 0) return fail(c, "ekpnp_collide_boundary_planes called twice");
+  launch_collide_walls(c);
+  if (c.z0 != 0) launch_collide_bulk(c, 0, 1);
+  if (c.z0 + c.nzl != c.p.nz) launch_collide_bulk(c, c.nzl - 1, c.nzl);
+  c.collide_phase = 1;
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_collide_interior_planes(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.collide_phase != 1) return fail(c, "ekpnp_collide_interior_planes without ekpnp_collide_boundary_planes");
+  int rc = collide_range(c, 1, c.nzl - 1, true);
+  if (rc) return rc;
+  finish_collide(c);
+  c.collide_phase = 0;
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_advance_time(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  c.t = c.t + c.p.dt;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+  launch_poisson_rhs(c);
+  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.work, (hipfftDoubleComplex*)c.spec));
+  launch_slab_thomas_local(c);
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_poisson_edge_buffer(ekpnp_ctx* ctx, int gathered, double** dptr, size_t* n) {
+  NEEDCTX(ctx);
+  if (c.nranks == 1 || !dptr || !n) return fail(c, "no edge buffers on a single-slab context");
+  const size_t per_rank = 4 * (size_t)c.p.ny * c.nxh;
+  *dptr = gathered ? c.edge_all : c.edge_local;
+  *n = gathered ? per_rank * c.nranks : per_rank;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+  launch_slab_reduce_correct(c);
+  FFTCHK(c, hipfftExecZ2D(c.plan_inv, (hipfftDoubleComplex*)c.spec, c.work));
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_phi_halo_pack(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  launch_phi_halo_pack(c);
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_poisson_stage3(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+  launch_phi_efield(c);
+  HIPCHK(c, hipGetLastError());
+  return EKPNP_OK;
+}

@@ -86,13 +86,16 @@ void launch_init_equilibrium(Ctx&);
 void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
 void launch_collide_walls(Ctx&);
 void launch_ghost_wrap(Ctx&);
-void launch_halo_pack(Ctx&);
+void launch_halo_pack(Ctx&, int buffer);
 void launch_halo_unpack(Ctx&);
 // poisson.hip
 void build_cprime(Ctx&);
 void launch_poisson_rhs(Ctx&);
 void launch_tridiag(Ctx&);
 void launch_phi_efield(Ctx&);
+void launch_slab_thomas_local(Ctx&);
+void launch_slab_reduce_correct(Ctx&);
+void launch_phi_halo_pack(Ctx&);
 
 struct Ctx {
   ekpnp_params p{};
@@ -113,6 +116,14 @@ struct Ctx {
   double* halo[4] = {};        // send-down, send-up, recv-from-below, recv-from-above
   size_t halo_doubles = 0;
   double* phi_halo[4] = {};
+  // distributed tridiagonal (slab contexts)
+  int slab_row_a = 0, slab_m = 0;  // first unknown row (local plane) and number of unknown rows
+  double* slab_u = nullptr;        // u = A^-1 e_1, [slab_m][modes]
+  double* u1um[2] = {};            // (u_1, u_m) of an edge slab (nzl-1 rows) / a middle slab (nzl rows)
+  double* edge_local = nullptr;    // [4][modes]
+  double* edge_all = nullptr;      // [nranks][4][modes]
+  double* phi_old = nullptr;       // PB relaxation state (ekpnp_pbe_begin/end)
+  int collide_phase = 0;           // 0 idle, 1 boundary planes done
   hipfftHandle plan_fwd = 0, plan_inv = 0;
   bool plans = false;
   double t = 0.0;

@@ -566,8 +566,8 @@ void launch_ghost_wrap(Ctx& c) {
                      (long long)(c.nzl + 2) * (long long)c.plane, c.nzl);
 }
 
-void launch_halo_pack(Ctx& c) {
-  double** p = c.pop[c.cur];
+void launch_halo_pack(Ctx& c, int buffer) {
+  double** p = c.pop[buffer];
   dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
   hipLaunchKernelGGL(k_halo_pack, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane,
                      (long long)(c.nzl + 2) * (long long)c.plane, c.nzl, c.halo[0], c.halo[1]);

@@ -113,10 +113,191 @@ __global__ void k_phi_efield(PArgs a) {
   a.fld[EKPNP_EZ][i] = 0.5 * (phi_at(a, x, y, ze - 1) - phi_at(a, x, y, ze + 1)) / a.dz;
 }
 
+// ------------------------------------------------------------------------------------------
+// z-slab version of the tridiagonal solve (no reference counterpart).
+// Rank r owns the unknown rows a..e of the global system (the interior planes of its slab,
+// m = e-a+1 of them).  With g_lo = x[a-1] and g_hi = x[e+1] (0 at a wall, the neighbour's edge
+// value at a slab interface) the local rows read  A x = r - g_lo e_1 - g_hi e_m,  A = tridiag(1,b,1),
+// hence  x = p - g_lo u - g_hi v,  p = A^-1 r,  u = A^-1 e_1,  v_k = u_{m+1-k}.
+// Stage 1 computes p (local Thomas) and publishes (p_1, p_m); after an all-gather every rank
+// solves the same 2(P-1)-unknown interface system per mode and corrects its rows.
+
+// u = A^-1 e_1 for an m-row block; stores the full vector and (u_1, u_m).
+__global__ void k_slab_unit_response(const double* __restrict__ cprime, int m, int nmodes, double* __restrict__ u, double* __restrict__ u1um) {
+  const int md = blockIdx.x * blockDim.x + threadIdx.x;
+  if (md >= nmodes) return;
+  const long long ms = nmodes;
+  const double* cp = cprime + md;
+  // forward: d'_1 = 1 * c'_1, d'_k = (0 - d'_{k-1}) c'_k ; the table row k of cprime is c'_k
+  // back:    u_m = d'_m, u_k = d'_k - c'_k u_{k+1}
+  // d' is kept in u between the two sweeps
+  double d = 0.0;
+  for (int k = 1; k <= m; ++k) {
+    d = ((k == 1 ? 1.0 : 0.0) - d) * cp[(long long)k * ms];
+    u[(long long)(k - 1) * ms + md] = d;
+  }
+  double x = d;
+  for (int k = m - 1; k >= 1; --k) {
+    x = u[(long long)(k - 1) * ms + md] - cp[(long long)k * ms] * x;
+    u[(long long)(k - 1) * ms + md] = x;
+  }
+  u1um[md] = x;       // u_1
+  u1um[ms + md] = d;  // u_m = d'_m
+}
+
+// stage 1: local Thomas solve of the owned unknown rows, in place; edges -> edge buffer
+// edge layout per rank: [4][nmodes] = p_first.re, p_first.im, p_last.re, p_last.im
+__global__ void k_slab_thomas_local(PArgs a, int row_a, int m, double* __restrict__ edge) {
+  const int md = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ms = (long long)a.ny * a.nxh;
+  if (md >= ms) return;
+  const double dz2 = a.dz * a.dz;
+  double2* s = a.spec + md + (long long)row_a * ms;  // local plane of the first unknown row
+  const double* cp = a.cprime + md;
+  double dr = 0.0, di = 0.0;
+#pragma unroll 4
+  for (int k = 1; k <= m; ++k) {
+    const double2 r = s[(long long)(k - 1) * ms];
+    const double c = cp[(long long)k * ms];
+    dr = (dz2 * r.x - dr) * c;
+    di = (dz2 * r.y - di) * c;
+    s[(long long)(k - 1) * ms] = make_double2(dr, di);
+  }
+  double pr = dr, pi = di;
+  edge[2 * ms + md] = pr;
+  edge[3 * ms + md] = pi;
+#pragma unroll 4
+  for (int k = m - 1; k >= 1; --k) {
+    const double2 d = s[(long long)(k - 1) * ms];
+    const double c = cp[(long long)k * ms];
+    pr = d.x - c * pr;
+    pi = d.y - c * pi;
+    s[(long long)(k - 1) * ms] = make_double2(pr, pi);
+  }
+  edge[md] = pr;
+  edge[ms + md] = pi;
+}
+
+// stage 2: interface system (block tridiagonal, 2x2 blocks, P-1 interfaces) + correction.
+// Interface i sits between slab i and i+1: X_i = x_last(slab i), Y_i = x_first(slab i+1):
+//   um_i X_{i-1} + X_i + u1_i Y_i             = p_last(i)
+//   u1_{i+1} X_i + Y_i + um_{i+1} Y_{i+1}     = p_first(i+1)
+// u1/um of slab j are those of its row count: type 0 (first/last slab, nzl-1 rows) or 1 (nzl).
+constexpr int MAXR = 16;
+__global__ void k_slab_reduce_correct(PArgs a, int rank, int nranks, int row_a, int m, const double* __restrict__ edges_all,
+                                      const double* __restrict__ u1um_edge, const double* __restrict__ u1um_mid,
+                                      const double* __restrict__ u) {
+  const int md = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ms = (long long)a.ny * a.nxh;
+  if (md >= ms) return;
+  const int ni = nranks - 1;
+  double u1[MAXR], um[MAXR];
+  for (int j = 0; j < nranks; ++j) {
+    const double* t = (j == 0 || j == nranks - 1) ? u1um_edge : u1um_mid;
+    u1[j] = t[md];
+    um[j] = t[ms + md];
+  }
+  // block Thomas.  D_i = [[1, u1_i],[u1_{i+1}, 1]], L_i = [[um_i,0],[0,0]], U_i = [[0,0],[0,um_{i+1}]]
+  // forward: D'_i = D_i - L_i D'^{-1}_{i-1} U_{i-1};  R'_i = R_i - L_i D'^{-1}_{i-1} R'_{i-1}
+  double d11[MAXR], d12[MAXR], d21[MAXR], d22[MAXR];
+  double rxr[MAXR], rxi[MAXR], ryr[MAXR], ryi[MAXR];
+  for (int i = 0; i < ni; ++i) {
+    const double* ei = edges_all + (long long)i * 4 * ms;        // slab i
+    const double* ej = edges_all + (long long)(i + 1) * 4 * ms;  // slab i+1
+    double a11 = 1.0, a12 = u1[i], a21 = u1[i + 1], a22 = 1.0;
+    double bxr = ei[2 * ms + md], bxi = ei[3 * ms + md];  // p_last(i)
+    double byr = ej[md], byi = ej[ms + md];               // p_first(i+1)
+    if (i > 0) {
+      // L_i D'^{-1}_{i-1}: only row 0, L = [[um_i,0],[0,0]] -> row0 = um_i * (first row of D'^{-1})
+      const double det = d11[i - 1] * d22[i - 1] - d12[i - 1] * d21[i - 1];
+      const double i11 = d22[i - 1] / det, i12 = -d12[i - 1] / det;  // first row of the inverse
+      const double l1 = um[i] * i11, l2 = um[i] * i12;
+      // U_{i-1} = [[0,0],[0,um_i]] -> (L D'^{-1} U) = [[0, l2*um_i],[0,0]]
+      a12 -= l2 * um[i];
+      bxr -= l1 * rxr[i - 1] + l2 * ryr[i - 1];
+      bxi -= l1 * rxi[i - 1] + l2 * ryi[i - 1];
+    }
+    d11[i] = a11; d12[i] = a12; d21[i] = a21; d22[i] = a22;
+    rxr[i] = bxr; rxi[i] = bxi; ryr[i] = byr; ryi[i] = byi;
+  }
+  // back substitution: Z_i = D'^{-1}_i (R'_i - U_i Z_{i+1}),  U_i Z_{i+1} = (0, um_{i+1} Y_{i+1})
+  double Xr[MAXR], Xi[MAXR], Yr[MAXR], Yi[MAXR];
+  for (int i = ni - 1; i >= 0; --i) {
+    double bxr = rxr[i], bxi = rxi[i], byr = ryr[i], byi = ryi[i];
+    if (i < ni - 1) {
+      byr -= um[i + 1] * Yr[i + 1];
+      byi -= um[i + 1] * Yi[i + 1];
+    }
+    const double det = d11[i] * d22[i] - d12[i] * d21[i];
+    Xr[i] = (d22[i] * bxr - d12[i] * byr) / det;
+    Xi[i] = (d22[i] * bxi - d12[i] * byi) / det;
+    Yr[i] = (-d21[i] * bxr + d11[i] * byr) / det;
+    Yi[i] = (-d21[i] * bxi + d11[i] * byi) / det;
+  }
+  const double glr = rank > 0 ? Xr[rank - 1] : 0.0, gli = rank > 0 ? Xi[rank - 1] : 0.0;
+  const double ghr = rank < nranks - 1 ? Yr[rank] : 0.0, ghi = rank < nranks - 1 ? Yi[rank] : 0.0;
+  // correction of the owned rows: x_k = p_k - g_lo u_k - g_hi u_{m+1-k}
+  double2* s = a.spec + md + (long long)row_a * ms;
+#pragma unroll 4
+  for (int k = 1; k <= m; ++k) {
+    const double uk = u[(long long)(k - 1) * ms + md];
+    const double vk = u[(long long)(m - k) * ms + md];
+    double2 p = s[(long long)(k - 1) * ms];
+    p.x -= glr * uk + ghr * vk;
+    p.y -= gli * uk + ghi * vk;
+    s[(long long)(k - 1) * ms] = p;
+  }
+}
+
+// phi of the slab's first and last plane (interior value or pinned wall value) for the neighbours
+__global__ void k_phi_halo_pack(PArgs a, double* __restrict__ send_dn, double* __restrict__ send_up) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.plane) return;
+  const int zb = a.z0, zt = a.z0 + a.nzl - 1;
+  send_dn[i] = zb == 0 ? a.voltage : a.work[i] * a.inv_nxny;
+  send_up[i] = zt == a.nz - 1 ? a.voltage2 : a.work[(long long)(a.nzl - 1) * a.plane + i] * a.inv_nxny;
+}
+
 void build_cprime(Ctx& c) {
   const int nm = c.p.ny * c.nxh;
-  hipLaunchKernelGGL(k_build_cprime, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.p.nx, c.p.ny, c.p.nz, c.nxh, c.p.Lx,
+  // single context: rows 1..nz-2 of the global system; slab: rows 1..nzl of a local block
+  const int rows_nz = c.nranks == 1 ? c.p.nz : c.nzl + 2;
+  hipLaunchKernelGGL(k_build_cprime, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.p.nx, c.p.ny, rows_nz, c.nxh, c.p.Lx,
                      c.p.Ly, c.p.dz);
+  if (c.nranks > 1) {
+    const bool edge_rank = (c.rank == 0 || c.rank == c.nranks - 1);
+    hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.slab_m, nm, c.slab_u,
+                       edge_rank ? c.u1um[0] : c.u1um[1]);
+    // (u_1, u_m) of the other slab type, through a scratch vector (set-up only)
+    const int m_other = edge_rank ? c.nzl : c.nzl - 1;
+    double* tmp = nullptr;
+    if (hipMalloc((void**)&tmp, (size_t)m_other * nm * sizeof(double)) == hipSuccess) {
+      hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, m_other, nm, tmp,
+                         edge_rank ? c.u1um[1] : c.u1um[0]);
+      (void)hipStreamSynchronize(c.stream);
+      (void)hipFree(tmp);
+    } else {
+      c.err = "scratch allocation for the slab unit response failed";
+    }
+  }
+}
+
+void launch_slab_thomas_local(Ctx& c) {
+  PArgs a = c.pargs();
+  const int nm = c.p.ny * c.nxh;
+  hipLaunchKernelGGL(k_slab_thomas_local, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.edge_local);
+}
+
+void launch_slab_reduce_correct(Ctx& c) {
+  PArgs a = c.pargs();
+  const int nm = c.p.ny * c.nxh;
+  hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.slab_row_a, c.slab_m,
+                     c.edge_all, c.u1um[0], c.u1um[1], c.slab_u);
+}
+
+void launch_phi_halo_pack(Ctx& c) {
+  PArgs a = c.pargs();
+  hipLaunchKernelGGL(k_phi_halo_pack, dim3((unsigned)((c.plane + 255) / 256)), dim3(256), 0, c.stream, a, c.phi_halo[0], c.phi_halo[1]);
 }
 
 void launch_poisson_rhs(Ctx& c) {

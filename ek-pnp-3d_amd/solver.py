@@ -119,6 +119,12 @@ def load_library():
         "ekpnp_poisson_stage3": (i32, [ctx]),
         "ekpnp_collide_boundary_planes": (i32, [ctx]),
         "ekpnp_collide_interior_planes": (i32, [ctx]),
+        "ekpnp_init_fields": (i32, [ctx]),
+        "ekpnp_pbe_begin": (i32, [ctx]),
+        "ekpnp_pbe_concentrations": (i32, [ctx]),
+        "ekpnp_pbe_relax": (i32, [ctx]),
+        "ekpnp_pbe_end": (i32, [ctx]),
+        "ekpnp_advance_time": (i32, [ctx]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it
@@ -242,6 +248,18 @@ class Solver:
         v = C.c_double()
         self._ck(self._L.ekpnp_get_time(self._h, C.byref(v)))
         return v.value
+
+    # -- z-slab pieces (driven by slab.py) ---------------------------------------------------
+    def call(self, name: str):
+        """Invoke a parameterless `int ekpnp_<name>(ctx)` entry point."""
+        self._ck(getattr(self._L, "ekpnp_" + name)(self._h))
+
+    def buffer(self, kind: str, which: int):
+        """(device pointer, n_doubles) of a halo / phi-halo / edge buffer."""
+        p, n = C.c_void_p(), C.c_size_t()
+        fn = {"halo": self._L.ekpnp_halo_buffer, "phi": self._L.ekpnp_phi_halo_buffer, "edge": self._L.ekpnp_poisson_edge_buffer}[kind]
+        self._ck(fn(self._h, which, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
 
     # -- measurement ------------------------------------------------------------------------
     def kernel_timing(self, enable: bool):

@@ -176,10 +176,21 @@ int ekpnp_poisson_edge_buffer(ekpnp_ctx* ctx, int gathered, double** device_ptr,
 int ekpnp_poisson_stage2(ekpnp_ctx* ctx);
 int ekpnp_phi_halo_pack(ekpnp_ctx* ctx);
 int ekpnp_poisson_stage3(ekpnp_ctx* ctx);
-/* Split form of ekpnp_stream_collide_save for halo/compute overlap:
- * boundary planes first (then pack + start the exchange), interior afterwards. */
+/* Split form of ekpnp_stream_collide_save for halo/compute overlap: the slab's first and last
+ * plane first (then ekpnp_halo_pack + start the exchange), the planes in between afterwards
+ * (overlapping the exchange), then ekpnp_halo_unpack once the exchange has landed. */
 int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx);
 int ekpnp_collide_interior_planes(ekpnp_ctx* ctx);
+/* The pieces of initialization() (LBM.cu:68-109) for a slab host, whose Poisson solve needs the
+ * transport between the stages: gpu_initialization (LBM.cu:111-128); the phi_old copy
+ * (LBM.cu:79-86); gpu_PBE (LBM.cu:139-146); gpu_PBE_phi + phi_old update (LBM.cu:98-104). */
+int ekpnp_init_fields(ekpnp_ctx* ctx);
+int ekpnp_pbe_begin(ekpnp_ctx* ctx);
+int ekpnp_pbe_concentrations(ekpnp_ctx* ctx);
+int ekpnp_pbe_relax(ekpnp_ctx* ctx);
+int ekpnp_pbe_end(ekpnp_ctx* ctx);
+/* t += dt (main.cu:200) for hosts that drive the split calls themselves. */
+int ekpnp_advance_time(ekpnp_ctx* ctx);
 
 #ifdef __cplusplus
 }

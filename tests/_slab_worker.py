@@ -1,0 +1,43 @@
+"""Worker of tests/test_slab_gpu.py: the true multi-process slab path (one process per rank, all
+on the one GPU of the test box, gloo transport staged through the host)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    pkg = G.load_package()
+    from ek_pnp_3d_amd.slab import DistributedSlab
+
+    out = os.environ["EKPNP_SLAB_OUT"]
+    nx, ny, nz = (int(v) for v in os.environ["EKPNP_SLAB_GRID"].split("x"))
+    p = pkg.default_params(nx, ny, nz)
+    p.pb_iterations = 12
+    run = DistributedSlab(p, rank, world, dist)
+    run.initialization()
+    s = run.solver
+    start = np.load(os.path.join(out, "start.npz"))
+    for k in ("rho", "c", "cn", "T", "ux", "uy", "uz"):
+        s.set_field(k, start[k][s.z0 : s.z0 + s.nz_local])
+    run.fast_Poisson()
+    run.init_equilibrium()
+    run.step(6)
+    run.synchronize()
+    np.savez(os.path.join(out, f"rank{rank}.npz"), z0=s.z0, **s.fields())
+    dist.barrier()
+    run.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+"""CPU coverage of the N>1 path: the transport (gloo, world_size 2 and 3, launched exactly like
+the driver launches bench.py) and the slab partition rule."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ring_transport_gloo(world, tmp_path):
+    ok = tmp_path / "ok"
+    env = dict(os.environ, EKPNP_RING_OK=str(ok), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_ring_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert ok.read_text() == f"ok {world}"
+
+
+def test_slab_extent_rules(pkg):
+    from ek_pnp_3d_amd.slab import slab_extent
+
+    assert slab_extent(512, 0, 1) == (0, 512)
+    assert [slab_extent(1024, r, 8) for r in (0, 3, 7)] == [(0, 128), (384, 128), (896, 128)]
+    with pytest.raises(ValueError):
+        slab_extent(51, 0, 2)
+    with pytest.raises(ValueError):
+        slab_extent(12, 0, 4)

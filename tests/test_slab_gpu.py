@@ -1,0 +1,99 @@
+"""GPU tests of the z-slab path: P slabs must reproduce the single-context
+result - the LBM part bit for bit (same kernels, same arithmetic per node), the Poisson part to
+rounding (the distributed tridiagonal associates differently)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _single(pkg, O, p, start, steps):
+    with pkg.Solver(p) as s:
+        s.initialization()
+        init = s.fields()
+        st = start(init)
+        s.set_fields(st)
+        s.fast_Poisson()
+        s.init_equilibrium()
+        s.step(steps)
+        return init, st, s.fields()
+
+
+@pytest.mark.parametrize("shape,nslabs", [((16, 12, 16), 2), ((20, 6, 24), 3), ((70, 5, 32), 4), ((16, 8, 64), 8)])
+def test_local_slab_group_equals_single_context(pkg, O, shape, nslabs):
+    from ek_pnp_3d_amd.slab import LocalSlabGroup
+
+    p = pkg.default_params(*shape)
+    p.pb_iterations = 15
+    po = O.default_params(*shape)
+    init1, st, want = _single(pkg, O, p, lambda f: O.perturb_fields(po, f), 7)
+    g = LocalSlabGroup(p, nslabs)
+    try:
+        g.initialization()
+        init = g.fields()
+        e0 = O.rel_l2(init, init1, {k: v for k, v in O.GROUPS.items() if k != "u"})
+        assert max(e0.values()) < 1e-12, e0
+        g.set_fields(st)
+        g.fast_Poisson()
+        g.init_equilibrium()
+        g.step(7)
+        got = g.fields()
+    finally:
+        g.close()
+    err = O.rel_l2(got, want)
+    assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err
+
+
+def test_slabs_three_lattices(pkg, O):
+    from ek_pnp_3d_amd.slab import LocalSlabGroup
+
+    shape = (24, 6, 20)
+    p = pkg.default_params(*shape)
+    p.pb_iterations, p.Ra, p.n_lattices = 10, 0.0, 3
+    po = O.default_params(*shape)
+    _, st, want = _single(pkg, O, p, lambda f: O.perturb_fields(po, f), 5)
+    g = LocalSlabGroup(p, 2)
+    try:
+        g.initialization()
+        g.set_fields(st)
+        g.fast_Poisson()
+        g.init_equilibrium()
+        g.step(5)
+        got = g.fields()
+    finally:
+        g.close()
+    err = O.rel_l2(got, want, {k: v for k, v in O.GROUPS.items() if k != "T"})
+    assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_processes_one_gpu_gloo(pkg, O, tmp_path):
+    """The real multi-process path (DistributedSlab + RingTransport), two ranks sharing the one
+    GPU of the box, launched like the driver launches bench.py."""
+    shape = (16, 12, 16)
+    p = pkg.default_params(*shape)
+    p.pb_iterations = 12
+    po = O.default_params(*shape)
+    _, st, want = _single(pkg, O, p, lambda f: O.perturb_fields(po, f), 6)
+    np.savez(tmp_path / "start.npz", **st)
+    env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_GRID="x".join(map(str, shape)), OMP_NUM_THREADS="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_slab_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    parts = sorted((np.load(tmp_path / f"rank{k}.npz") for k in range(2)), key=lambda d: int(d["z0"]))
+    got = {k: np.concatenate([d[k] for d in parts], axis=0) for k in O.FIELDS}
+    err = O.rel_l2(got, want)
+    assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err

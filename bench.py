@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--ic", default="perturbed", choices=["perturbed", "uniform"])
     ap.add_argument("--pb-iterations", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="transport of the N>1 path; gloo (host-staged) only to rehearse the multi-rank flow")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: put every rank on device 0")
     args = ap.parse_args()
 
     import torch
@@ -155,9 +158,10 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     pkg = G.load_package()
-    O = G.load_oracle() if False else None  # the oracle is only used by cpu_baseline()
 
     free_b, total_b = torch.cuda.mem_get_info()
     wname, (nx, ny, nz), nl = parse_workload(args.workload, free_b)
@@ -165,7 +169,10 @@ def main():
     if world > 1:
         import torch.distributed as dist  # noqa: WPS440
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
         nz_global = nz * world  # weak scaling: one cfg-sized slab per GPU
     else:
         nz_global = nz
@@ -217,7 +224,7 @@ def main():
     sol.kernel_timing(False)
 
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

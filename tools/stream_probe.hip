@@ -1,0 +1,139 @@
+// stream_probe.hip — what streaming rate can the bulk kernel's access pattern reach on this GPU?
+// Variants of a pure copy (no arithmetic): 8 vs 16 bytes per lane, aligned vs shifted by one
+// double, plain vs non-temporal stores, and the LBM shape: 27 direction streams read and 27
+// written per workgroup with the D3Q27 pull offsets.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void k8(const double* __restrict__ a, double* __restrict__ b, size_t n, int sh) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = a[i + sh];
+}
+__global__ void k8nt(const double* __restrict__ a, double* __restrict__ b, size_t n, int sh) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i + sh), b + i);
+}
+__global__ void k16(const double* __restrict__ a, double* __restrict__ b, size_t n, int sh) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i + 1 < n) {
+    double v0, v1;
+    if (sh == 0) { double2 v = *(const double2*)(a + i); v0 = v.x; v1 = v.y; }
+    else { v0 = a[i + sh]; v1 = a[i + sh + 1]; }
+    *(double2*)(b + i) = make_double2(v0, v1);
+  }
+}
+typedef double d2 __attribute__((ext_vector_type(2)));
+__global__ void k16u(const double* __restrict__ a, double* __restrict__ b, size_t n, int sh) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i + 1 < n) {
+    d2 v;
+    __builtin_memcpy(&v, a + i + sh, 16);  // unaligned 16-byte load
+    *(d2*)(b + i) = v;
+  }
+}
+// LBM shape: nd direction streams, plane-strided, pull offsets in x (+-1), y and z rows
+__global__ void klbm(const double* __restrict__ a, double* __restrict__ b, int nx, int ny, int nz, long long dstride, int nd, int nt) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, z = blockIdx.z + 1;
+  if (x >= nx) return;
+  const int xm = x == 0 ? nx - 1 : x - 1, xp = x + 1 == nx ? 0 : x + 1;
+  const int ym = y == 0 ? ny - 1 : y - 1, yp = y + 1 == ny ? 0 : y + 1;
+  const long long o = ((long long)z * ny + y) * nx + x;
+  double acc[27];
+#pragma unroll
+  for (int d = 0; d < 27; ++d) {
+    if (d < nd) {
+      const int cx = (d % 3) - 1, cy = ((d / 3) % 3) - 1, cz = (d / 9) - 1;
+      const int xs = cx < 0 ? xp : cx > 0 ? xm : x, ys = cy < 0 ? yp : cy > 0 ? ym : y;
+      acc[d] = a[(long long)d * dstride + ((long long)(z - cz) * ny + ys) * nx + xs];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 27; ++d)
+    if (d < nd) {
+      if (nt) __builtin_nontemporal_store(acc[d], b + (long long)d * dstride + o);
+      else b[(long long)d * dstride + o] = acc[d];
+    }
+}
+
+// the same traffic with a tiled (AoSoA) layout: [z][y][x/64][27][64]
+__global__ void klbm_tiled(const double* __restrict__ a, double* __restrict__ b, int nx, int ny, int nz, int nd) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, z = blockIdx.z + 1;
+  if (x >= nx) return;
+  const int nxt = nx / 64;
+  const int xm = x == 0 ? nx - 1 : x - 1, xp = x + 1 == nx ? 0 : x + 1;
+  const int ym = y == 0 ? ny - 1 : y - 1, yp = y + 1 == ny ? 0 : y + 1;
+  const unsigned ox[3] = {(unsigned)((xp >> 6) * 27 * 64 + (xp & 63)), (unsigned)((x >> 6) * 27 * 64 + (x & 63)), (unsigned)((xm >> 6) * 27 * 64 + (xm & 63))};
+  double acc[27];
+#pragma unroll
+  for (int d = 0; d < 27; ++d) {
+    if (d < nd) {
+      const int cx = (d % 3) - 1, cy = ((d / 3) % 3) - 1, cz = (d / 9) - 1;
+      const int ys = cy < 0 ? yp : cy > 0 ? ym : y;
+      const double* row = a + ((long long)(z - cz) * ny + ys) * (long long)nxt * 27 * 64 + d * 64;
+      acc[d] = row[ox[cx + 1]];
+    }
+  }
+  double* orow = b + ((long long)z * ny + y) * (long long)nxt * 27 * 64;
+#pragma unroll
+  for (int d = 0; d < 27; ++d)
+    if (d < nd) orow[d * 64 + ox[1]] = acc[d];
+}
+
+template <class F>
+static void timeit(const char* name, double bytes, F f) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  f();
+  CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < 5; ++r) {
+    CK(hipEventRecord(e0)); f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  printf("%-34s %8.3f ms  %7.1f GB/s\n", name, best, bytes / best / 1e6);
+  fflush(stdout);
+}
+
+int main() {
+  const size_t n = (size_t)1 << 29;  // 4 GiB per array
+  double *a, *b;
+  CK(hipMalloc(&a, (n + 16) * 8)); CK(hipMalloc(&b, (n + 16) * 8));
+  CK(hipMemset(a, 0, (n + 16) * 8)); CK(hipMemset(b, 0, (n + 16) * 8));
+  const double bytes = 16.0 * n;
+  dim3 g8((unsigned)(n / 256)), g16((unsigned)(n / 512)), blk(256);
+  timeit("copy 8B/lane aligned", bytes, [&] { hipLaunchKernelGGL(k8, g8, blk, 0, 0, a, b, n, 0); });
+  timeit("copy 8B/lane shifted", bytes, [&] { hipLaunchKernelGGL(k8, g8, blk, 0, 0, a, b, n, 1); });
+  timeit("copy 8B/lane nt ld+st", bytes, [&] { hipLaunchKernelGGL(k8nt, g8, blk, 0, 0, a, b, n, 0); });
+  timeit("copy 8B/lane nt shifted", bytes, [&] { hipLaunchKernelGGL(k8nt, g8, blk, 0, 0, a, b, n, 1); });
+  timeit("copy 16B/lane aligned", bytes, [&] { hipLaunchKernelGGL(k16, g16, blk, 0, 0, a, b, n, 0); });
+  timeit("copy 16B/lane 2x8B shifted loads", bytes, [&] { hipLaunchKernelGGL(k16, g16, blk, 0, 0, a, b, n, 1); });
+  timeit("copy 16B/lane unaligned x4 load", bytes, [&] { hipLaunchKernelGGL(k16u, g16, blk, 0, 0, a, b, n, 1); });
+  CK(hipFree(a)); CK(hipFree(b));
+  // LBM-shaped: 512x512x(130) planes, 27 streams
+  const int nx = 512, ny = 512, nz = 130;
+  const long long dstride = (long long)nx * ny * (nz + 2);
+  CK(hipMalloc(&a, dstride * 27 * 8)); CK(hipMalloc(&b, dstride * 27 * 8));
+  CK(hipMemset(a, 0, dstride * 27 * 8)); CK(hipMemset(b, 0, dstride * 27 * 8));
+  const double lb = 16.0 * 27 * nx * ny * (double)nz;
+  for (int bx : {64, 128, 256}) {
+    dim3 g(nx / bx, ny, nz), bb(bx);
+    char nm[64];
+    snprintf(nm, sizeof nm, "lbm-shape 27 streams, block %d", bx);
+    timeit(nm, lb, [&] { hipLaunchKernelGGL(klbm, g, bb, 0, 0, a, b, nx, ny, nz, dstride, 27, 0); });
+    snprintf(nm, sizeof nm, "lbm-shape 27 streams nt, block %d", bx);
+    timeit(nm, lb, [&] { hipLaunchKernelGGL(klbm, g, bb, 0, 0, a, b, nx, ny, nz, dstride, 27, 1); });
+  }
+  for (int bx : {64, 256}) {
+    dim3 g(nx / bx, ny, nz), bb(bx);
+    char nm[64];
+    snprintf(nm, sizeof nm, "lbm-shape TILED [z][y][xt][27][64], block %d", bx);
+    timeit(nm, lb, [&] { hipLaunchKernelGGL(klbm_tiled, g, bb, 0, 0, a, b, nx, ny, nz, 27); });
+  }
+  return 0;
+}

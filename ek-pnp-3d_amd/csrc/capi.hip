@@ -11,10 +11,6 @@
 
 using namespace ekpnp;
 
-struct ekpnp_ctx {
-  Ctx c;
-};
-
 static thread_local std::string g_create_err;
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -247,6 +243,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (c.edge_local) (void)hipFree(c.edge_local);
   if (c.edge_all) (void)hipFree(c.edge_all);
   if (c.phi_old) (void)hipFree(c.phi_old);
+  if (c.diag) (void)hipFree(c.diag);
   for (int k = 0; k < 4; ++k) {
     if (c.halo[k]) (void)hipFree(c.halo[k]);
     if (c.phi_halo[k]) (void)hipFree(c.phi_halo[k]);

@@ -96,6 +96,10 @@ void launch_phi_efield(Ctx&);
 void launch_slab_thomas_local(Ctx&);
 void launch_slab_reduce_correct(Ctx&);
 void launch_phi_halo_pack(Ctx&);
+// diag.hip
+constexpr int DIAG_SCRATCH = 1024 + 8;
+void launch_current(Ctx&, double* scratch);
+void launch_umax(Ctx&, double* scratch);
 
 struct Ctx {
   ekpnp_params p{};
@@ -123,6 +127,7 @@ struct Ctx {
   double* edge_local = nullptr;    // [4][modes]
   double* edge_all = nullptr;      // [nranks][4][modes]
   double* phi_old = nullptr;       // PB relaxation state (ekpnp_pbe_begin/end)
+  double* diag = nullptr;          // reduction scratch (DIAG_SCRATCH doubles)
   int collide_phase = 0;           // 0 idle, 1 boundary planes done
   hipfftHandle plan_fwd = 0, plan_inv = 0;
   bool plans = false;
@@ -140,3 +145,8 @@ struct Ctx {
 };
 
 }  // namespace ekpnp
+
+// the opaque handle of include/ekpnp.h
+struct ekpnp_ctx {
+  ekpnp::Ctx c;
+};

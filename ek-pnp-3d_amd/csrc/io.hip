@@ -1,0 +1,163 @@
+// io.hip — diagnostics and the main.cu IO surface behind the C ABI.
+//
+//   double current(c, cn, ez)             LBM.cu:2674-2710, main.cu:211-216  -> ekpnp_current
+//   record_umax(FILE*, t, ux, uy, uz)     LBM.cu:2712-2753, main.cu:221      -> ekpnp_umax, ekpnp_record_umax
+//   save_data_tecplot(FILE*, t, ..., 1)   LBM.cu:2492-2565, main.cu:179,207  -> ekpnp_save_data_tecplot
+//   save_data_end(FILE*, t, ...)          LBM.cu:2567-2630, main.cu:256      -> ekpnp_save_data_end
+//   read_data(&t, ...)                    LBM.cu:2632-2671, main.cu:163      -> ekpnp_read_data
+// The writers keep the reference's text formats byte for byte (Tecplot POINT zones, the lossy
+// "%10.6f" restart file) and its wall extrapolation of rho, c, cn, u (LBM.cu:2527-2542); a FILE*
+// cannot cross a C ABI, so they take a path and an append flag.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ekpnp_internal.h"
+
+using namespace ekpnp;
+
+#define NEEDCTX(ctx)                    \
+  if (!(ctx)) return EKPNP_ERR_INVALID; \
+  Ctx& c = (ctx)->c
+#define HIPCHK(ctx, call)                                                  \
+  do {                                                                     \
+    hipError_t e_ = (call);                                                \
+    if (e_ != hipSuccess) {                                                \
+      (ctx).err = std::string(#call) + ": " + hipGetErrorString(e_);       \
+      return EKPNP_ERR_HIP;                                                \
+    }                                                                      \
+  } while (0)
+
+static int fail(Ctx& c, const char* msg) {
+  c.err = msg;
+  return EKPNP_ERR_INVALID;
+}
+
+static int need_scratch(Ctx& c) {
+  if (!c.diag) HIPCHK(c, hipMalloc((void**)&c.diag, DIAG_SCRATCH * sizeof(double)));
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_current(ekpnp_ctx* ctx, double* I) {
+  NEEDCTX(ctx);
+  if (!I) return fail(c, "NULL pointer");
+  *I = 0.0;
+  if (c.z0 + c.nzl != c.p.nz) return EKPNP_OK;  // this slab does not hold the upper plate: contributes 0
+  if (c.nzl < 3) return fail(c, "the upper slab needs 3 planes for the wall extrapolation");
+  int rc = need_scratch(c);
+  if (rc) return rc;
+  launch_current(c, c.diag);
+  double s = 0.0;
+  HIPCHK(c, hipMemcpyAsync(&s, c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  *I = s * c.p.K * c.p.dz * c.p.dz;  // LBM.cu:2708
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_umax(ekpnp_ctx* ctx, double* umax) {
+  NEEDCTX(ctx);
+  if (!umax) return fail(c, "NULL pointer");
+  int rc = need_scratch(c);
+  if (rc) return rc;
+  launch_umax(c, c.diag);
+  double s = 0.0;
+  HIPCHK(c, hipMemcpyAsync(&s, c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  *umax = s;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_record_umax(ekpnp_ctx* ctx, const char* path, int append, double time) {
+  NEEDCTX(ctx);
+  if (!path) return fail(c, "NULL path");
+  double um = 0.0;
+  int rc = ekpnp_umax(ctx, &um);
+  if (rc) return rc;
+  FILE* f = std::fopen(path, append ? "ab" : "wb");
+  if (!f) return fail(c, "cannot open umax file");
+  std::fprintf(f, "%10.6f %10.6f\n", time, um);  // LBM.cu:2748
+  std::fclose(f);
+  return EKPNP_OK;
+}
+
+// host copies of the 11 fields, with the reference's wall extrapolation of rho, c, cn, u
+static int fetch_fields(Ctx& c, std::vector<std::vector<double>>& h, bool extrapolate) {
+  if (c.nranks != 1) return fail(c, "file IO is implemented for single-slab contexts");
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  h.assign(EKPNP_NFIELDS, std::vector<double>(c.nloc));
+  for (int i = 0; i < EKPNP_NFIELDS; ++i) HIPCHK(c, hipMemcpy(h[i].data(), c.fld[i], c.nloc * sizeof(double), hipMemcpyDeviceToHost));
+  if (extrapolate) {  // LBM.cu:2527-2542 / 2596-2611
+    const size_t pl = c.plane, nz = c.p.nz;
+    const int ids[6] = {EKPNP_RHO, EKPNP_C, EKPNP_CN, EKPNP_UX, EKPNP_UY, EKPNP_UZ};
+    for (int k = 0; k < 6; ++k) {
+      double* a = h[ids[k]].data();
+      for (size_t i = 0; i < pl; ++i) {
+        a[i] = 2.0 * a[pl + i] - a[2 * pl + i];
+        a[(nz - 1) * pl + i] = 2.0 * a[(nz - 2) * pl + i] - a[(nz - 3) * pl + i];
+      }
+    }
+  }
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_save_data_tecplot(ekpnp_ctx* ctx, const char* path, int append, double time, int first) {
+  NEEDCTX(ctx);
+  if (!path) return fail(c, "NULL path");
+  std::vector<std::vector<double>> h;
+  int rc = fetch_fields(c, h, true);
+  if (rc) return rc;
+  FILE* f = std::fopen(path, append ? "ab" : "wb");
+  if (!f) return fail(c, "cannot open Tecplot file");
+  if (first)  // LBM.cu:2546-2548
+    std::fprintf(f, "%s\n", "VARIABLES=\"x\",\"y\",\"z\",\"u\",\"v\",\"w\",\"p\",\"charge\",\"neg charge\",\"phi\",\"Ex\",\"Ey\",\"Ez\",\"Temperature\"");
+  std::fprintf(f, "\n");
+  std::fprintf(f, "ZONE T=\"t=%g\", F=POINT, I = %d, J = %d, K = %d\n", time, c.p.nx, c.p.ny, c.p.nz);  // LBM.cu:2551
+  const double dx = c.p.dx, dy = c.p.dy, dz = c.p.dz;
+  size_t i = 0;
+  for (unsigned z = 0; z < (unsigned)c.p.nz; ++z)
+    for (unsigned y = 0; y < (unsigned)c.p.ny; ++y)
+      for (unsigned x = 0; x < (unsigned)c.p.nx; ++x, ++i)
+        std::fprintf(f, "%g %g %g %g %g %g %g %g %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f\n", dx * x, dy * y, dz * z, h[EKPNP_UX][i],
+                     h[EKPNP_UY][i], h[EKPNP_UZ][i], h[EKPNP_RHO][i], h[EKPNP_C][i], h[EKPNP_CN][i], h[EKPNP_PHI][i], h[EKPNP_EX][i],
+                     h[EKPNP_EY][i], h[EKPNP_EZ][i], h[EKPNP_T][i]);  // LBM.cu:2559-2561
+  const bool bad = std::ferror(f) != 0;
+  std::fclose(f);
+  return bad ? fail(c, "write error on Tecplot file") : EKPNP_OK;
+}
+
+extern "C" int ekpnp_save_data_end(ekpnp_ctx* ctx, const char* path, int append, double time) {
+  NEEDCTX(ctx);
+  if (!path) return fail(c, "NULL path");
+  std::vector<std::vector<double>> h;
+  int rc = fetch_fields(c, h, true);
+  if (rc) return rc;
+  FILE* f = std::fopen(path, append ? "ab" : "wb");
+  if (!f) return fail(c, "cannot open restart file");
+  for (size_t i = 0; i < c.nloc; ++i)  // LBM.cu:2619-2622
+    std::fprintf(f, "%10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f\n", time, h[EKPNP_UX][i],
+                 h[EKPNP_UY][i], h[EKPNP_UZ][i], h[EKPNP_RHO][i], h[EKPNP_C][i], h[EKPNP_CN][i], h[EKPNP_PHI][i], h[EKPNP_EX][i],
+                 h[EKPNP_EY][i], h[EKPNP_EZ][i], h[EKPNP_T][i]);
+  const bool bad = std::ferror(f) != 0;
+  std::fclose(f);
+  return bad ? fail(c, "write error on restart file") : EKPNP_OK;
+}
+
+extern "C" int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time) {
+  NEEDCTX(ctx);
+  if (!path || !time) return fail(c, "NULL pointer");
+  if (c.nranks != 1) return fail(c, "file IO is implemented for single-slab contexts");
+  FILE* f = std::fopen(path, "r");
+  if (!f) return fail(c, "cannot open restart file");
+  std::vector<std::vector<double>> h(EKPNP_NFIELDS, std::vector<double>(c.nloc));
+  bool ok = true;
+  for (size_t i = 0; ok && i < c.nloc; ++i)  // LBM.cu:2652-2655
+    ok = std::fscanf(f, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf", time, &h[EKPNP_UX][i], &h[EKPNP_UY][i], &h[EKPNP_UZ][i],
+                     &h[EKPNP_RHO][i], &h[EKPNP_C][i], &h[EKPNP_CN][i], &h[EKPNP_PHI][i], &h[EKPNP_EX][i], &h[EKPNP_EY][i], &h[EKPNP_EZ][i],
+                     &h[EKPNP_T][i]) == 12;
+  std::fclose(f);
+  if (!ok) return fail(c, "restart file is shorter than the lattice or malformed");
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  for (int i = 0; i < EKPNP_NFIELDS; ++i) HIPCHK(c, hipMemcpy(c.fld[i], h[i].data(), c.nloc * sizeof(double), hipMemcpyHostToDevice));
+  c.t = *time;
+  return EKPNP_OK;
+}

@@ -125,6 +125,12 @@ def load_library():
         "ekpnp_pbe_relax": (i32, [ctx]),
         "ekpnp_pbe_end": (i32, [ctx]),
         "ekpnp_advance_time": (i32, [ctx]),
+        "ekpnp_current": (i32, [ctx, pd]),
+        "ekpnp_umax": (i32, [ctx, pd]),
+        "ekpnp_record_umax": (i32, [ctx, C.c_char_p, i32, dbl]),
+        "ekpnp_save_data_tecplot": (i32, [ctx, C.c_char_p, i32, dbl, i32]),
+        "ekpnp_save_data_end": (i32, [ctx, C.c_char_p, i32, dbl]),
+        "ekpnp_read_data": (i32, [ctx, C.c_char_p, pd]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it
@@ -248,6 +254,31 @@ class Solver:
         v = C.c_double()
         self._ck(self._L.ekpnp_get_time(self._h, C.byref(v)))
         return v.value
+
+    # -- diagnostics and IO (LBM.cu:2492-2753) -----------------------------------------------
+    def current(self) -> float:
+        v = C.c_double()
+        self._ck(self._L.ekpnp_current(self._h, C.byref(v)))
+        return v.value
+
+    def umax(self) -> float:
+        v = C.c_double()
+        self._ck(self._L.ekpnp_umax(self._h, C.byref(v)))
+        return v.value
+
+    def record_umax(self, path: str, time: float, append: bool = True):
+        self._ck(self._L.ekpnp_record_umax(self._h, os.fsencode(path), int(append), float(time)))
+
+    def save_data_tecplot(self, path: str, time: float, first: bool = True, append: bool = False):
+        self._ck(self._L.ekpnp_save_data_tecplot(self._h, os.fsencode(path), int(append), float(time), int(first)))
+
+    def save_data_end(self, path: str, time: float, append: bool = False):
+        self._ck(self._L.ekpnp_save_data_end(self._h, os.fsencode(path), int(append), float(time)))
+
+    def read_data(self, path: str) -> float:
+        t = C.c_double()
+        self._ck(self._L.ekpnp_read_data(self._h, os.fsencode(path), C.byref(t)))
+        return t.value
 
     # -- z-slab pieces (driven by slab.py) ---------------------------------------------------
     def call(self, name: str):

@@ -148,6 +148,25 @@ int ekpnp_set_time(ekpnp_ctx* ctx, double t);
 /* Lattice geometry of this context: global nz, first owned plane, owned planes. */
 int ekpnp_local_extent(ekpnp_ctx* ctx, int* z0, int* nz_local);
 
+/* ---- diagnostics and the main.cu IO surface ------- */
+/* double current(double* c, double* cn, double* ez) — LBM.h:179, LBM.cu:2674-2710, called at
+ * main.cu:211-216: I = K dz^2 sum_{x,y} (c - cn) Ez on the upper plate after the linear wall
+ * extrapolation of c, cn.  Reduced on the device (wavefront shuffles); a slab that does not
+ * hold the upper plate returns 0, so the ranks' values add up. */
+int ekpnp_current(ekpnp_ctx* ctx, double* I);
+/* the number record_umax prints (LBM.h:180, LBM.cu:2712-2753): max(0, max uz) over this
+ * context's planes; ekpnp_record_umax appends the reference's "%10.6f %10.6f\n" line. */
+int ekpnp_umax(ekpnp_ctx* ctx, double* umax);
+int ekpnp_record_umax(ekpnp_ctx* ctx, const char* path, int append, double time);
+/* void save_data_tecplot(FILE*, double time, r, c, cn, fi, u, v, w, ex, ey, ez, temp, int first)
+ * — LBM.h:169, LBM.cu:2492-2565: one Tecplot POINT zone (header when first != 0), byte-compatible. */
+int ekpnp_save_data_tecplot(ekpnp_ctx* ctx, const char* path, int append, double time, int first);
+/* void save_data_end(FILE*, double time, ...) — LBM.h:170, LBM.cu:2567-2630 (12 columns %10.6f). */
+int ekpnp_save_data_end(ekpnp_ctx* ctx, const char* path, int append, double time);
+/* void read_data(double* time, r, c, cn, fi, u, v, w, ex, ey, ez, temp) — LBM.h:160,
+ * LBM.cu:2632-2671: fills the 11 fields from a save_data_end file (main.cu:161-164). */
+int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time);
+
 /* ---- measurement hooks (bench.py; no reference counterpart) ------------------ */
 /* When enabled, every launch of the bulk collide/stream kernel is bracketed by
  * HIP events on the context's stream; the sum is returned by ..._get. */

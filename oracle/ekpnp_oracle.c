@@ -752,6 +752,34 @@ void oracle_step_shifts(oracle_state* s, const double* shifts, int nsteps) {
   s->dc_shift = 0.0;
 }
 
+/* double current(c, cn, ez), LBM.cu:2674-2710: works on host copies, so the fields are untouched */
+double oracle_current(oracle_state* s) {
+  const ekpnp_params* p = &s->p;
+  const int NZ = p->nz;
+  const double* c = s->fld[EKPNP_C];
+  const double* cn = s->fld[EKPNP_CN];
+  const double* ez = s->fld[EKPNP_EZ];
+  double I = 0;
+  for (int y = 0; y < p->ny; y++)
+    for (int x = 0; x < p->nx; x++) {
+      /* LBM.cu:2689-2690: the upper-plate values current() sums are the extrapolated ones */
+      double ce = 2.0 * c[sidx(s, x, y, NZ - 2)] - c[sidx(s, x, y, NZ - 3)];
+      double cne = 2.0 * cn[sidx(s, x, y, NZ - 2)] - cn[sidx(s, x, y, NZ - 3)];
+      I += (ce - cne) * ez[sidx(s, x, y, NZ - 1)]; /* LBM.cu:2704-2706 */
+    }
+  I = I * p->K * p->dz * p->dz; /* LBM.cu:2708 */
+  return I;
+}
+
+/* the value record_umax prints, LBM.cu:2712-2753: umax = MAX(0, uz) over all nodes (the wall
+ * extrapolation there touches ux, uy only, LBM.cu:2728-2732) */
+double oracle_umax(oracle_state* s) {
+  double umax = 0;
+  const double* uz = s->fld[EKPNP_UZ];
+  for (size_t i = 0; i < s->n; ++i) umax = (umax > uz[i]) ? umax : uz[i];
+  return umax;
+}
+
 /* main.cu:189-200 */
 void oracle_step(oracle_state* s, int nsteps) {
   for (int i = 0; i < nsteps; ++i) {

@@ -81,6 +81,9 @@ def lib():
         for fn in ("oracle_initialization_shifts", "oracle_step_shifts"):
             getattr(L, fn).argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
             getattr(L, fn).restype = None
+        for fn in ("oracle_current", "oracle_umax"):
+            getattr(L, fn).argtypes = [C.c_void_p]
+            getattr(L, fn).restype = C.c_double
         L.oracle_set_num_threads.argtypes = [C.c_int]
         L.oracle_set_num_threads.restype = None
         L.oracle_get_max_threads.restype = C.c_int
@@ -177,6 +180,12 @@ class Oracle:
     def initialization_shifts(self, shifts):
         a = np.ascontiguousarray(shifts, dtype=np.float64)
         lib().oracle_initialization_shifts(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size)
+
+    def current(self) -> float:
+        return lib().oracle_current(self._h)
+
+    def umax(self) -> float:
+        return lib().oracle_umax(self._h)
 
     # -- sub-kernels -----------------------------------------------------------------------
     def collide_save(self):

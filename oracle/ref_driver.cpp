@@ -20,6 +20,8 @@
  *            upload 11 fields, fast_Poisson, init_equilibrium, steps; dumps <tag>_step0.bin,
  *            <tag>_step<n>.bin and <tag>_step_trace.bin ([1+steps][2][NZ])
  *        ref_driver <outdir> poisson <in.bin> <tag>     -> upload fields, one fast_Poisson, dump
+ *        ref_driver <outdir> io <in.bin> <tag>          -> upload fields; the reference's own
+ *            save_data_tecplot (2 zones), save_data_end, record_umax and current() on them
  *        --set name=value writes a __constant__/__device__ physics symbol of LBM.h at run time
  *        (exf uw chargeinf voltage voltage2 Ext Ra TH): no source edit, hipMemcpyToSymbol only.
  * The phi columns let the tests measure the reference's DC-mode leak (poisson.cu:177) of every
@@ -49,6 +51,13 @@ static void dump(const std::string& path) {
   }
   fclose(f);
   printf("wrote %s\n", path.c_str());
+  /* the reference's wall-current diagnostic, exactly as main.cu:211-215 calls it */
+  CHECK(hipMemcpy(charge_host, charge_gpu, mem_size_scalar, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(chargen_host, chargen_gpu, mem_size_scalar, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(Ez_host, Ez_gpu, mem_size_scalar, hipMemcpyDeviceToHost));
+  double cur = current(charge_host, chargen_host, Ez_host);
+  FILE* g = fopen((path + ".current").c_str(), "wb");
+  if (g) { fwrite(&cur, sizeof(double), 1, g); fclose(g); }
 }
 
 static void upload(const char* path) {
@@ -239,6 +248,29 @@ int main(int argc, char** argv) {
       dump(out + "/" + tag + "_step" + std::to_string(mark) + ".bin");
     }
     write_trace(out + "/" + tag + "_step_trace.bin");
+  } else if (mode == "io" && args.size() >= 3) {
+    /* the reference's writers on uploaded fields: two Tecplot zones (first = 1, then 0), the
+     * restart file and one umax line, as main.cu:179,207,221,256 produce them */
+    upload(args[1].c_str());
+    std::string tag = args[2];
+    FILE* f = fopen((out + "/" + tag + "_data.dat").c_str(), "wb+");
+    save_data_tecplot(f, 1.25e-8, rho_gpu, charge_gpu, chargen_gpu, phi_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu, 1);
+    save_data_tecplot(f, 2.5e-8, rho_gpu, charge_gpu, chargen_gpu, phi_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu, 0);
+    fclose(f);
+    FILE* e = fopen((out + "/" + tag + "_data_end.dat").c_str(), "wb+");
+    save_data_end(e, 1.25e-8, rho_gpu, charge_gpu, chargen_gpu, phi_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
+    fclose(e);
+    FILE* u = fopen((out + "/" + tag + "_umax.dat").c_str(), "wb+");
+    record_umax(u, 1.25e-8, ux_gpu, uy_gpu, uz_gpu);
+    fclose(u);
+    CHECK(hipMemcpy(charge_host, charge_gpu, mem_size_scalar, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(chargen_host, chargen_gpu, mem_size_scalar, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(Ez_host, Ez_gpu, mem_size_scalar, hipMemcpyDeviceToHost));
+    double cur = current(charge_host, chargen_host, Ez_host);
+    FILE* g = fopen((out + "/" + tag + "_current.bin").c_str(), "wb");
+    fwrite(&cur, sizeof(double), 1, g);
+    fclose(g);
+    printf("wrote %s io files, current = %.17g\n", tag.c_str(), cur);
   } else if (mode == "poisson" && args.size() >= 3) {
     upload(args[1].c_str());
     fast_Poisson(charge_gpu, chargen_gpu, kx, ky, kz, plan);

@@ -38,8 +38,30 @@ def read_bin(path):
     return {k: a[i * N : (i + 1) * N].reshape(SHAPE).copy() for i, k in enumerate(O.FIELDS)}
 
 
+def read_current(path):
+    return float(np.fromfile(path + ".current", dtype=np.float64)[0])
+
+
 def write_bin(path, f):
     np.concatenate([np.ascontiguousarray(f[k], dtype=np.float64).ravel() for k in O.FIELDS]).tofile(path)
+
+
+def io_fields(seed=6):
+    """Seeded fields with realistic magnitudes for the IO / diagnostics golden (G6)."""
+    rng = np.random.default_rng(seed)
+    f = {}
+    f["rho"] = 1000.0 + 1e-3 * rng.standard_normal(SHAPE)
+    f["c"] = 0.0105 + 1e-3 * rng.random(SHAPE)
+    f["cn"] = 0.0095 + 1e-3 * rng.random(SHAPE)
+    f["phi"] = -5e-3 * rng.random(SHAPE)
+    f["ux"] = 1e-4 * rng.standard_normal(SHAPE)
+    f["uy"] = 1e-4 * rng.standard_normal(SHAPE)
+    f["uz"] = 1e-4 * rng.standard_normal(SHAPE)
+    f["Ex"] = 1e2 * rng.standard_normal(SHAPE)
+    f["Ey"] = 1e2 * rng.standard_normal(SHAPE)
+    f["Ez"] = 5e4 * rng.standard_normal(SHAPE)
+    f["T"] = rng.random(SHAPE)
+    return f
 
 
 def main(outdir):
@@ -65,6 +87,7 @@ def main(outdir):
     for tag, f in [("init", init)] + [(f"step{m}", read_bin(os.path.join(tmp, f"g1_step{m}.bin"))) for m in (1, 5, 20, 100)]:
         for k, v in f.items():
             g1[f"{tag}_{k}"] = v
+    g1["current"] = np.array([read_current(os.path.join(tmp, f"g1_step{m}.bin")) for m in (1, 5, 20, 100)])
     g1["init_trace"] = trace(os.path.join(tmp, "g1_init_trace.bin"), 501)
     g1["step_trace"] = trace(os.path.join(tmp, "g1_step_trace.bin"), 100)
     np.savez_compressed(os.path.join(outdir, "ref_g1_full.npz"), **g1)
@@ -81,6 +104,7 @@ def main(outdir):
         f = read_bin(os.path.join(tmp, f"g2_step{m}.bin"))
         for k, v in f.items():
             g2[f"step{m}_{k}"] = v
+    g2["current"] = np.array([read_current(os.path.join(tmp, f"g2_step{m}.bin")) for m in (1, 2, 50)])
     g2["step_trace"] = trace(os.path.join(tmp, "g2_step_trace.bin"), 51)
     np.savez_compressed(os.path.join(outdir, "ref_g2_full.npz"), **g2)
 
@@ -109,6 +133,25 @@ def main(outdir):
     for k in ("phi", "Ex", "Ey", "Ez"):
         g5["out_" + k] = out5[k]
     np.savez_compressed(os.path.join(outdir, "ref_g5_full.npz"), **g5)
+    # ---- G6: the reference's writers and diagnostics on seeded random fields
+    f6 = io_fields()
+    inp6 = os.path.join(tmp, "g6_in.bin")
+    write_bin(inp6, f6)
+    run("io", inp6, "g6")
+    import hashlib
+    import shutil
+
+    g6 = {"input_sha256": np.array(hashlib.sha256(open(inp6, "rb").read()).hexdigest())}
+    for name in ("data.dat", "data_end.dat", "umax.dat"):
+        raw = open(os.path.join(tmp, "g6_" + name), "rb").read()
+        g6[name + "_sha256"] = np.array(hashlib.sha256(raw).hexdigest())
+        g6[name + "_size"] = np.array(len(raw))
+        lines = raw.split(b"\n")
+        g6[name + "_head"] = np.array(b"\n".join(lines[:6]).decode())
+        g6[name + "_tail"] = np.array(b"\n".join(lines[-3:]).decode())
+    g6["current"] = np.fromfile(os.path.join(tmp, "g6_current.bin"), dtype=np.float64)[0]
+    np.savez_compressed(os.path.join(outdir, "ref_g6.npz"), **g6)
+    shutil.copy(os.path.join(tmp, "g6_data_end.dat"), os.path.join(outdir, "g6_data_end.dat"))
     print("golden vectors written to", outdir)
 
 

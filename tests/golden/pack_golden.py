@@ -77,6 +77,8 @@ def main(src, dst):
         o.efield()
     print("G1: max |phi_ref - phi_exact - shift| over 601 solves:", worst)
     out = {"marks": g1["marks"], "init_shifts": np.array(init_shifts), "step_shifts": np.array(step_shifts)}
+    if "current" in g1.files:
+        out["current"] = g1["current"]  # double current(c, cn, ez), LBM.cu:2674-2710, at the marks
     for tag in ["init"] + [f"step{m}" for m in g1["marks"]]:
         for k in O.FIELDS:
             out[f"{tag}_{k}"] = g1[f"{tag}_{k}"][:, 0, 0].copy()  # z profile (x-y uniform, asserted above)
@@ -103,6 +105,12 @@ def main(src, dst):
         o.efield()
     print("G2: max |phi_ref - phi_exact - shift| over 51 solves:", worst)
     out = {"marks": g2["marks"], "shifts": np.array(shifts), "ysel": np.array(YSEL)}
+    if "current" in g2.files:
+        out["current"] = g2["current"]
+        for m in g2["marks"]:  # what current() reads: c, cn on the three top planes, Ez on the top plane
+            out[f"cur{m}_c"] = g2[f"step{m}_c"][-3:].copy()
+            out[f"cur{m}_cn"] = g2[f"step{m}_cn"][-3:].copy()
+            out[f"cur{m}_Ez"] = g2[f"step{m}_Ez"][-1].copy()
     for k in ("rho", "c", "cn", "T", "ux", "uy", "uz"):
         out["input_" + k] = g2["input_" + k]
     for m in [0] + list(g2["marks"]):
@@ -128,6 +136,11 @@ def main(src, dst):
     for k in ("phi", "Ex", "Ey", "Ez"):
         out["out_" + k] = g5["out_" + k][:, YSEL, :].copy()
     np.savez_compressed(os.path.join(dst, "ref_g5.npz"), **out)
+    # ---- G6 (IO byte-compatibility + diagnostics): already small, passed through
+    if os.path.exists(os.path.join(src, "ref_g6.npz")):
+        import shutil
+
+        shutil.copy(os.path.join(src, "ref_g6.npz"), os.path.join(dst, "ref_g6.npz"))
     for f in ("ref_g1.npz", "ref_g2.npz", "ref_g3.npz", "ref_g5.npz"):
         print(f, os.path.getsize(os.path.join(dst, f)), "bytes")
 

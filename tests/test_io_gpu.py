@@ -1,0 +1,110 @@
+"""GPU tests of the §8(f) rows: on-device diagnostics and the main.cu IO surface.
+The writers are checked BYTE FOR BYTE against files written by the reference's own
+save_data_tecplot / save_data_end / record_umax (sha256 in tests/golden/ref_g6.npz, produced by
+oracle/_ref/ref_driver in `io` mode on seeded fields)."""
+import hashlib
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mirror(pkg, po):
+    p = pkg.Params()
+    for name, _ in p._fields_:
+        setattr(p, name, getattr(po, name))
+    return p
+
+
+def _io_fields():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.io_fields()
+
+
+def _sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def test_current_and_umax_on_device_vs_oracle(pkg, O):
+    po = O.default_params(40, 12, 17)
+    po.pb_iterations = 20
+    orc = O.Oracle(po)
+    orc.initialization()
+    start = O.perturb_fields(po, orc.fields())
+    orc.set_fields(start); orc.fast_poisson(); orc.init_equilibrium(); orc.step(12)
+    with pkg.Solver(_mirror(pkg, po)) as s:
+        s.initialization(); s.set_fields(start); s.fast_Poisson(); s.init_equilibrium(); s.step(12)
+        cur, um = s.current(), s.umax()
+        # and on exactly the oracle's fields: only the summation order differs
+        s.set_fields(orc.fields())
+        cur2, um2 = s.current(), s.umax()
+    assert abs(cur2 - orc.current()) <= 1e-13 * abs(orc.current())
+    assert um2 == orc.umax()
+    assert abs(cur - orc.current()) <= 1e-9 * abs(orc.current())
+    assert abs(um - orc.umax()) <= 1e-7 * abs(orc.umax())
+
+
+def test_umax_is_zero_when_nothing_moves_up(pkg):
+    p = pkg.default_params(16, 4, 8)
+    with pkg.Solver(p) as s:
+        s.set_field("uz", -np.ones(s.shape))
+        assert s.umax() == 0.0  # LBM.cu:2718: umax starts at 0
+
+
+def test_writers_byte_compatible_with_the_reference(pkg, O, tmp_path):
+    g = np.load(golden_path("ref_g6.npz")) if os.path.exists(golden_path("ref_g6.npz")) else None
+    if g is None:
+        pytest.skip("ref_g6.npz missing")
+    f = _io_fields()
+    raw = np.concatenate([np.ascontiguousarray(f[k], dtype=np.float64).ravel() for k in O.FIELDS]).tobytes()
+    if hashlib.sha256(raw).hexdigest() != str(g["input_sha256"]):
+        pytest.skip("numpy's random stream differs from the one the golden was made with")
+    po = O.default_params(50, 8, 51)
+    po.Lx, po.Ly, po.Lz = 0.5e-6, 0.08e-6, 0.5e-6
+    with pkg.Solver(_mirror(pkg, po)) as s:
+        s.set_fields(f)
+        d = str(tmp_path / "data.dat")
+        s.save_data_tecplot(d, 1.25e-8, first=True, append=False)
+        s.save_data_tecplot(d, 2.5e-8, first=False, append=True)
+        e = str(tmp_path / "data_end.dat")
+        s.save_data_end(e, 1.25e-8)
+        u = str(tmp_path / "umax.dat")
+        s.record_umax(u, 1.25e-8, append=False)
+        cur = s.current()
+        for name, path in (("data.dat", d), ("data_end.dat", e), ("umax.dat", u)):
+            assert os.path.getsize(path) == int(g[name + "_size"]), name
+            head = "\n".join(open(path).read().split("\n")[:6])
+            assert head == str(g[name + "_head"]), name
+            assert _sha(path) == str(g[name + "_sha256"]), name
+        assert abs(cur - float(g["current"])) <= 1e-13 * abs(float(g["current"]))
+        # read_data (LBM.cu:2632-2671) on that byte-identical restart file
+        with pkg.Solver(_mirror(pkg, po)) as r:
+            t = r.read_data(e)
+            assert t == float("%10.6f" % 1.25e-8)
+            ext = {k: np.array(v, copy=True) for k, v in f.items()}
+            for k in ("rho", "c", "cn", "ux", "uy", "uz"):  # the writer extrapolates these to the walls
+                ext[k][0] = 2 * ext[k][1] - ext[k][2]
+                ext[k][-1] = 2 * ext[k][-2] - ext[k][-3]
+            for k in O.FIELDS:
+                want = np.array([float("%10.6f" % v) for v in ext[k].ravel()]).reshape(ext[k].shape)
+                assert np.array_equal(r.get_field(k), want), k
+
+
+def test_io_errors_are_returned(pkg, tmp_path):
+    p = pkg.default_params(8, 4, 6)
+    with pkg.Solver(p) as s:
+        with pytest.raises(pkg.EkpnpError):
+            s.read_data(str(tmp_path / "missing.dat"))
+        (tmp_path / "short.dat").write_text("0 0 0 0 0 0 0 0 0 0 0 0\n")
+        with pytest.raises(pkg.EkpnpError):
+            s.read_data(str(tmp_path / "short.dat"))
+        with pytest.raises(pkg.EkpnpError):
+            s.save_data_end(str(tmp_path / "no_such_dir" / "x.dat"), 0.0)

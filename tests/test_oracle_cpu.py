@@ -249,3 +249,42 @@ def test_golden_G5_poisson_alone(O):
     o.fast_poisson(0.0)
     d = g["out_phi"][1:-1] - o.field("phi")[1:-1][:, ys, :]
     assert np.abs(d - float(g["shift"])).max() < 1e-16
+
+
+# ---- diagnostics ---------------------------------------------------
+
+def test_current_and_umax_restate_the_reference_loops(O):
+    p = O.default_params(12, 7, 9)
+    o = O.Oracle(p)
+    rng = np.random.default_rng(11)
+    c, cn, ez, uz = (rng.random(o.shape) for _ in range(4))
+    o.set_fields({"c": c, "cn": cn, "Ez": ez, "uz": uz - 0.5})
+    ce = 2 * c[-2] - c[-3]
+    cne = 2 * cn[-2] - cn[-3]
+    want = ((ce - cne) * ez[-1]).sum() * p.K * p.dz * p.dz  # LBM.cu:2689-2708
+    assert abs(o.current() - want) <= 1e-13 * abs(want)
+    assert o.umax() == max(0.0, (uz - 0.5).max())  # LBM.cu:2718,2744
+    o.set_fields({"uz": -uz})
+    assert o.umax() == 0.0
+    assert np.array_equal(o.field("c"), c)  # current() works on host copies in the reference
+
+
+def test_golden_current_of_the_reference_runs(O):
+    """double current(c, cn, ez) evaluated by the reference itself at the marks of G1/G2/G6."""
+    g2 = _need("ref_g2.npz")
+    if "current" not in g2.files:
+        pytest.skip("fixtures predate the current() golden")
+    p = _ref_grid(O)
+    o = O.Oracle(p)
+    for i, m in enumerate(int(v) for v in g2["marks"]):
+        c = np.zeros(o.shape); cn = np.zeros(o.shape); ez = np.zeros(o.shape)
+        c[-3:], cn[-3:], ez[-1] = g2[f"cur{m}_c"], g2[f"cur{m}_cn"], g2[f"cur{m}_Ez"]
+        o.set_fields({"c": c, "cn": cn, "Ez": ez})
+        want = float(g2["current"][i])
+        assert abs(o.current() - want) <= 1e-14 * abs(want), (m, o.current(), want)
+    g1 = _need("ref_g1.npz")
+    for i, m in enumerate(int(v) for v in g1["marks"]):
+        bc = lambda k: np.broadcast_to(g1[f"step{m}_{k}"][:, None, None], o.shape)  # noqa: E731
+        o.set_fields({"c": bc("c"), "cn": bc("cn"), "Ez": bc("Ez")})
+        want = float(g1["current"][i])
+        assert abs(o.current() - want) <= 1e-13 * abs(want), (m, o.current(), want)

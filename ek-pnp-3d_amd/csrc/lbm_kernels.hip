@@ -14,6 +14,7 @@
 // collides its own lattice.  All 27 loads and 27 stores of a wave are 512-byte contiguous row
 // segments (x is the fastest index, LBM.cu:27-30); row bases are wave-uniform (SGPR) and only
 // the three x offsets live in VGPRs.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -143,16 +144,22 @@ __device__ __forceinline__ void equilibrium(const KArgs& a, double m, double vx,
 // ------------------------------------------------------------------------------------------
 // bulk kernel: every owned plane that is not a wall plane
 
+#ifndef EKPNP_BULK_MIN_WAVES
+#define EKPNP_BULK_MIN_WAVES 1  // tuning knob: min waves per SIMD the register allocator must allow
+#endif
 template <int NL, bool PULL>
-__global__ void __launch_bounds__(64 * NL) k_collide_bulk(const KArgs a, const int zl_begin, const int nrows, const int nxb) {
+__global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(const KArgs a, const int zl_begin, const int nrows, const int nxb, const int rchunk) {
   __shared__ double mom[7][64];
-  // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs, so give each XCD
-  // whole x rows (consecutive `slot`s of one XCD walk along x, then to the next row): the
-  // cache lines straddled by two neighbouring 64-node segments are then served by one L2.
+  // XCD-aware placement.  Workgroups are dealt round-robin over the 8 XCDs (bid % 8 picks the
+  // XCD).  Each XCD is given runs of `rchunk` CONSECUTIVE x rows (and walks along x inside a row),
+  // so that every one of the 27+27 direction streams is sequential per XCD instead of a 1-in-8
+  // row comb.  Measured on cfg3 (512^3, 4 lattices): 45.0 ms with rows dealt one by one,
+  // 43.0 ms with runs of >= 8 rows (profiles/r01_sweep_map.log); 64 is used.
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
-  const int row = (slot / nxb) * 8 + xcd;
-  const int xb = slot - (slot / nxb) * nxb;
+  const int r = slot / nxb;
+  const int xb = slot - r * nxb;
+  const int row = ((r / rchunk) * 8 + xcd) * rchunk + r % rchunk;
   if (row >= nrows) return;  // whole workgroup leaves together
   const int y = row % a.ny;
   const int zl = zl_begin + row / a.ny;
@@ -216,7 +223,13 @@ __global__ void __launch_bounds__(64 * NL) k_collide_bulk(const KArgs a, const i
   const long long orow = ((long long)zg * a.ny + y) * (long long)a.nx + xc;
   auto store = [&](auto ic, double v) {
     constexpr int d = decltype(ic)::value;
+    // non-temporal: the populations written here are not read again before the next step
+    // (+1 % on cfg3, profiles/r01_sweep_libs.log); EKPNP_PLAIN_STORES builds the A/B partner
+#ifdef EKPNP_PLAIN_STORES
     if (act) dst[(long long)d * a.dstride + orow] = v;
+#else
+    if (act) __builtin_nontemporal_store(v, dst + (long long)d * a.dstride + orow);
+#endif
   };
   if (lat == 0) {
     if (act) {  // LBM.cu:807-810
@@ -520,12 +533,15 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
   const int nrows = (zl_end - zl_begin) * c.p.ny;
   if (nrows <= 0) return;
   const int nxb = (c.p.nx + 63) / 64;
-  const int rows8 = (nrows + 7) / 8 * 8;
-  dim3 g((unsigned)((long long)rows8 * nxb)), b(64 * NL);
+  static const int rchunk_env = std::getenv("EKPNP_BULK_RCHUNK") ? std::atoi(std::getenv("EKPNP_BULK_RCHUNK")) : 64;  // tuning knob
+  const int rchunk = rchunk_env < 1 ? 1 : rchunk_env;
+  // rows per XCD, rounded up to whole runs: the 8 XCDs together cover [0, 8*per_xcd) >= nrows
+  const long long per_xcd = ((long long)nrows + 8LL * rchunk - 1) / (8LL * rchunk) * rchunk;
+  dim3 g((unsigned)(8 * per_xcd * nxb)), b(64 * NL);
   if (c.streamed_state)
-    hipLaunchKernelGGL((k_collide_bulk<NL, false>), g, b, 0, c.stream, a, zl_begin, nrows, nxb);
+    hipLaunchKernelGGL((k_collide_bulk<NL, false>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
   else
-    hipLaunchKernelGGL((k_collide_bulk<NL, true>), g, b, 0, c.stream, a, zl_begin, nrows, nxb);
+    hipLaunchKernelGGL((k_collide_bulk<NL, true>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
 }
 
 void launch_collide_bulk(Ctx& c, int zl_begin, int zl_end) {

@@ -97,20 +97,37 @@ __device__ __forceinline__ double phi_at(const PArgs& a, int x, int y, int z /*g
   return a.work[((long long)zl * a.ny + y) * a.nx + x] * a.inv_nxny;
 }
 
-__global__ void k_phi_efield(PArgs a) {
+constexpr int PHI_ZCHUNK = 16;
+
+// One thread marches up a column of PHI_ZCHUNK planes with phi(z-1), phi(z), phi(z+1) in
+// registers: every phi value is read once for the three z uses (the x+-1 / y+-1 neighbours come
+// from the same or the adjacent row, i.e. from cache).
+__global__ void __launch_bounds__(256) k_phi_efield(PArgs a) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= a.nx) return;
   const int y = blockIdx.y;
-  const int zl = blockIdx.z;
-  const int z = a.z0 + zl;
-  const long long i = ((long long)zl * a.ny + y) * a.nx + x;
+  const int zl0 = blockIdx.z * PHI_ZCHUNK;
+  const int zl1 = min(zl0 + PHI_ZCHUNK, a.nzl);
   const int xp1 = x + 1 == a.nx ? 0 : x + 1, xm1 = x == 0 ? a.nx - 1 : x - 1;
   const int yp1 = y + 1 == a.ny ? 0 : y + 1, ym1 = y == 0 ? a.ny - 1 : y - 1;
-  a.fld[EKPNP_PHI][i] = phi_at(a, x, y, z);
-  a.fld[EKPNP_EX][i] = 0.5 * (phi_at(a, xm1, y, z) - phi_at(a, xp1, y, z)) / a.dx;
-  a.fld[EKPNP_EY][i] = 0.5 * (phi_at(a, x, ym1, z) - phi_at(a, x, yp1, z)) / a.dy;
-  const int ze = z == 0 ? 1 : (z == a.nz - 1 ? a.nz - 2 : z);  // gpu_bc: wall Ez <- neighbour's Ez
-  a.fld[EKPNP_EZ][i] = 0.5 * (phi_at(a, x, y, ze - 1) - phi_at(a, x, y, ze + 1)) / a.dz;
+  const double hx = 0.5 / a.dx, hy = 0.5 / a.dy, hz = 0.5 / a.dz;
+  double pm = phi_at(a, x, y, a.z0 + zl0 - 1);
+  double p0 = phi_at(a, x, y, a.z0 + zl0);
+  for (int zl = zl0; zl < zl1; ++zl) {
+    const int z = a.z0 + zl;
+    const double pp = phi_at(a, x, y, z + 1);
+    const long long i = ((long long)zl * a.ny + y) * a.nx + x;
+    a.fld[EKPNP_PHI][i] = p0;
+    a.fld[EKPNP_EX][i] = (phi_at(a, xm1, y, z) - phi_at(a, xp1, y, z)) * hx;
+    a.fld[EKPNP_EY][i] = (phi_at(a, x, ym1, z) - phi_at(a, x, yp1, z)) * hy;
+    double ez;
+    if (z == 0) ez = (p0 - phi_at(a, x, y, 2)) * hz;                          // gpu_bc: Ez(0) <- Ez(1)
+    else if (z == a.nz - 1) ez = (phi_at(a, x, y, a.nz - 3) - p0) * hz;        // gpu_bc: Ez(NZ-1) <- Ez(NZ-2)
+    else ez = (pm - pp) * hz;
+    a.fld[EKPNP_EZ][i] = ez;
+    pm = p0;
+    p0 = pp;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -314,7 +331,7 @@ void launch_tridiag(Ctx& c) {
 void launch_phi_efield(Ctx& c) {
   PArgs a = c.pargs();
   const int bx = c.p.nx >= 256 ? 256 : 64;
-  hipLaunchKernelGGL(k_phi_efield, dim3((c.p.nx + bx - 1) / bx, c.p.ny, c.nzl), dim3(bx), 0, c.stream, a);
+  hipLaunchKernelGGL(k_phi_efield, dim3((c.p.nx + bx - 1) / bx, c.p.ny, (c.nzl + PHI_ZCHUNK - 1) / PHI_ZCHUNK), dim3(bx), 0, c.stream, a);
 }
 
 }  // namespace ekpnp

@@ -51,7 +51,8 @@ class Params(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, _LIBNAME)
+    # EKPNP_LIBRARY: A/B a differently built libekpnp.so (tools/sweep.sh); never a fallback
+    return os.environ.get("EKPNP_LIBRARY") or os.path.join(_HERE, _LIBNAME)
 
 
 def exported_symbols() -> list:

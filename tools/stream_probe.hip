@@ -59,6 +59,36 @@ __global__ void klbm(const double* __restrict__ a, double* __restrict__ b, int n
     }
 }
 
+// LBM shape with the bulk kernel's XCD-chunked row mapping (1-D grid), nl lattices = nl waves per
+// block on separate arrays (a + l*lstride), like k_collide_bulk
+__global__ void klbm_chunk(const double* __restrict__ a, double* __restrict__ b, int nx, int ny, int nz, long long dstride, long long lstride,
+                           int nxb, int rchunk, int nt) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int r = slot / nxb, xb = slot - r * nxb;
+  const int row = ((r / rchunk) * 8 + xcd) * rchunk + r % rchunk;
+  if (row >= ny * nz) return;
+  const int lat = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = xb * 64 + lane, y = row % ny, z = row / ny + 1;
+  const double* aa = a + lat * lstride;
+  double* bb = b + lat * lstride;
+  const int xm = x == 0 ? nx - 1 : x - 1, xp = x + 1 == nx ? 0 : x + 1;
+  const int ym = y == 0 ? ny - 1 : y - 1, yp = y + 1 == ny ? 0 : y + 1;
+  const long long o = ((long long)z * ny + y) * nx + x;
+  double acc[27];
+#pragma unroll
+  for (int d = 0; d < 27; ++d) {
+    const int cx = (d % 3) - 1, cy = ((d / 3) % 3) - 1, cz = (d / 9) - 1;
+    const int xs = cx < 0 ? xp : cx > 0 ? xm : x, ys = cy < 0 ? yp : cy > 0 ? ym : y;
+    acc[d] = aa[(long long)d * dstride + ((long long)(z - cz) * ny + ys) * nx + xs];
+  }
+#pragma unroll
+  for (int d = 0; d < 27; ++d) {
+    if (nt) __builtin_nontemporal_store(acc[d], bb + (long long)d * dstride + o);
+    else bb[(long long)d * dstride + o] = acc[d];
+  }
+}
+
 // the same traffic with a tiled (AoSoA) layout: [z][y][x/64][27][64]
 __global__ void klbm_tiled(const double* __restrict__ a, double* __restrict__ b, int nx, int ny, int nz, int nd) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,11 +159,28 @@ int main() {
     snprintf(nm, sizeof nm, "lbm-shape 27 streams nt, block %d", bx);
     timeit(nm, lb, [&] { hipLaunchKernelGGL(klbm, g, bb, 0, 0, a, b, nx, ny, nz, dstride, 27, 1); });
   }
-  for (int bx : {64, 256}) {
+  CK(hipFree(a)); CK(hipFree(b));
+  {
+    // 4 lattices, 512x512x128 each: 4 x 27 x 130 planes
+    const int nzc = 128;
+    const long long ds = (long long)nx * ny * (nzc + 2), ls = ds * 27;
+    CK(hipMalloc(&a, ls * 4 * 8)); CK(hipMalloc(&b, ls * 4 * 8));
+    CK(hipMemset(a, 0, ls * 4 * 8)); CK(hipMemset(b, 0, ls * 4 * 8));
+    const double lb4 = 16.0 * 27 * 4 * nx * ny * (double)nzc;
+    const int nxb = nx / 64;
+    for (int rc : {1, 8, 64}) for (int nt : {0, 1}) {
+      const long long nrows = (long long)ny * nzc;
+      const long long per = (nrows + 8LL * rc - 1) / (8LL * rc) * rc;
+      char nm[80];
+      snprintf(nm, sizeof nm, "lbm-shape 4 lattices x 27, rchunk %d%s", rc, nt ? " nt" : "");
+      timeit(nm, lb4, [&] { hipLaunchKernelGGL(klbm_chunk, dim3((unsigned)(8 * per * nxb)), dim3(256), 0, 0, a, b, nx, ny, nzc, ds, ls, nxb, rc, nt); });
+    }
+  }
+  for (int bx : {64}) {
     dim3 g(nx / bx, ny, nz), bb(bx);
     char nm[64];
     snprintf(nm, sizeof nm, "lbm-shape TILED [z][y][xt][27][64], block %d", bx);
-    timeit(nm, lb, [&] { hipLaunchKernelGGL(klbm_tiled, g, bb, 0, 0, a, b, nx, ny, nz, 27); });
+    if (false) timeit(nm, lb, [&] { hipLaunchKernelGGL(klbm_tiled, g, bb, 0, 0, a, b, nx, ny, nz, 27); });
   }
   return 0;
 }

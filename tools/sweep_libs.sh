@@ -1,0 +1,16 @@
+#!/bin/bash
+# sweep_libs.sh — A/B differently built libekpnp variants (EKPNP_LIBRARY) on one box.
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+WL="${1:-cfg3}"
+for rep in 1 2; do
+for v in ${VARIANTS:-base}; do
+  lib="$ROOT/ek-pnp-3d_amd/libekpnp_$v.so"; [ "$v" = base ] && lib="$ROOT/ek-pnp-3d_amd/libekpnp.so"
+  echo -n "variant=$v rep=$rep: "
+  EKPNP_LIBRARY=$lib timeout -k 10 300 python3 $ROOT/bench.py --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --ic uniform 2>/dev/null | python3 -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print(d['value'], 'MLUPS', d['ms_per_step'], 'ms/step; bulk', d['roofline']['avg_launch_ms'], 'ms', d['roofline']['achieved'], 'GB/s')
+"
+done
+done

@@ -102,11 +102,21 @@ constexpr int PHI_ZCHUNK = 16;
 // One thread marches up a column of PHI_ZCHUNK planes with phi(z-1), phi(z), phi(z+1) in
 // registers: every phi value is read once for the three z uses (the x+-1 / y+-1 neighbours come
 // from the same or the adjacent row, i.e. from cache).
-__global__ void __launch_bounds__(256) k_phi_efield(PArgs a) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+//
+// XCD-aware placement as in k_collide_bulk: the (y, z-chunk) rows are dealt to the 8 XCDs in
+// runs of 64 consecutive y, so the y+-1 neighbour rows are found in the XCD's own L2 (with rows
+// dealt one by one every L2 fetched all three rows: 4.1 GB fetched for 1.07 GB of phi).
+__global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, const int nrows) {
+  constexpr int RCHUNK = 64;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int r = slot / nxb, xb = slot - r * nxb;
+  const int row = ((r / RCHUNK) * 8 + xcd) * RCHUNK + r % RCHUNK;
+  if (row >= nrows) return;
+  const int x = xb * blockDim.x + threadIdx.x;
   if (x >= a.nx) return;
-  const int y = blockIdx.y;
-  const int zl0 = blockIdx.z * PHI_ZCHUNK;
+  const int y = row % a.ny;
+  const int zl0 = (row / a.ny) * PHI_ZCHUNK;
   const int zl1 = min(zl0 + PHI_ZCHUNK, a.nzl);
   const int xp1 = x + 1 == a.nx ? 0 : x + 1, xm1 = x == 0 ? a.nx - 1 : x - 1;
   const int yp1 = y + 1 == a.ny ? 0 : y + 1, ym1 = y == 0 ? a.ny - 1 : y - 1;
@@ -331,7 +341,10 @@ void launch_tridiag(Ctx& c) {
 void launch_phi_efield(Ctx& c) {
   PArgs a = c.pargs();
   const int bx = c.p.nx >= 256 ? 256 : 64;
-  hipLaunchKernelGGL(k_phi_efield, dim3((c.p.nx + bx - 1) / bx, c.p.ny, (c.nzl + PHI_ZCHUNK - 1) / PHI_ZCHUNK), dim3(bx), 0, c.stream, a);
+  const int nxb = (c.p.nx + bx - 1) / bx;
+  const int nrows = c.p.ny * ((c.nzl + PHI_ZCHUNK - 1) / PHI_ZCHUNK);
+  const long long per_xcd = ((long long)nrows + 8 * 64 - 1) / (8 * 64) * 64;
+  hipLaunchKernelGGL(k_phi_efield, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
 }
 
 }  // namespace ekpnp

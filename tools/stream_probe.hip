@@ -89,6 +89,43 @@ __global__ void klbm_chunk(const double* __restrict__ a, double* __restrict__ b,
   }
 }
 
+// lattice-interleaved layout [d][z][y][x][4]: one 32-byte element holds the four lattices'
+// population of direction d at a node; wave w of the block owns a quarter of the directions.
+struct __attribute__((aligned(32))) quad { double v[4]; };
+__global__ void klbm_inter(const quad* __restrict__ a, quad* __restrict__ b, int nx, int ny, int nz, long long dstride, int nxb, int rchunk, int nt) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int r = slot / nxb, xb = slot - r * nxb;
+  const int row = ((r / rchunk) * 8 + xcd) * rchunk + r % rchunk;
+  if (row >= ny * nz) return;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = xb * 64 + lane, y = row % ny, z = row / ny + 1;
+  const int xm = x == 0 ? nx - 1 : x - 1, xp = x + 1 == nx ? 0 : x + 1;
+  const int ym = y == 0 ? ny - 1 : y - 1, yp = y + 1 == ny ? 0 : y + 1;
+  const long long o = ((long long)z * ny + y) * nx + x;
+  quad acc[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int d = wv * 7 + k;
+    if (d < 27) {
+      const int cx = (d % 3) - 1, cy = ((d / 3) % 3) - 1, cz = (d / 9) - 1;
+      const int xs = cx < 0 ? xp : cx > 0 ? xm : x, ys = cy < 0 ? yp : cy > 0 ? ym : y;
+      acc[k] = a[(long long)d * dstride + ((long long)(z - cz) * ny + ys) * nx + xs];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int d = wv * 7 + k;
+    if (d < 27) {
+      if (nt) {
+        double* q = (double*)(b + (long long)d * dstride + o);
+        __builtin_nontemporal_store(acc[k].v[0], q); __builtin_nontemporal_store(acc[k].v[1], q + 1);
+        __builtin_nontemporal_store(acc[k].v[2], q + 2); __builtin_nontemporal_store(acc[k].v[3], q + 3);
+      } else b[(long long)d * dstride + o] = acc[k];
+    }
+  }
+}
+
 // the same traffic with a tiled (AoSoA) layout: [z][y][x/64][27][64]
 __global__ void klbm_tiled(const double* __restrict__ a, double* __restrict__ b, int nx, int ny, int nz, int nd) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,6 +211,19 @@ int main() {
       char nm[80];
       snprintf(nm, sizeof nm, "lbm-shape 4 lattices x 27, rchunk %d%s", rc, nt ? " nt" : "");
       timeit(nm, lb4, [&] { hipLaunchKernelGGL(klbm_chunk, dim3((unsigned)(8 * per * nxb)), dim3(256), 0, 0, a, b, nx, ny, nzc, ds, ls, nxb, rc, nt); });
+    }
+  }
+  {
+    const int nzc = 128;
+    const long long ds = (long long)nx * ny * (nzc + 2);
+    const double lb4 = 16.0 * 27 * 4 * nx * ny * (double)nzc;
+    const int nxb = nx / 64;
+    for (int rc : {1, 8, 64}) for (int nt : {0, 1}) {
+      const long long nrows = (long long)ny * nzc;
+      const long long per = (nrows + 8LL * rc - 1) / (8LL * rc) * rc;
+      char nm[80];
+      snprintf(nm, sizeof nm, "lbm-shape INTERLEAVED [d][z][y][x][4], rchunk %d%s", rc, nt ? " nt" : "");
+      timeit(nm, lb4, [&] { hipLaunchKernelGGL(klbm_inter, dim3((unsigned)(8 * per * nxb)), dim3(256), 0, 0, (const quad*)a, (quad*)b, nx, ny, nzc, ds, nxb, rc, nt); });
     }
   }
   for (int bx : {64}) {

@@ -105,9 +105,12 @@ KArgs Ctx::kargs() const {
   a.dt = dt;
   a.F = p.convertCtoCharge; a.Ext = p.Ext; a.exf = p.exf;
   a.rho0 = p.rho0; a.Ra = p.Ra; a.nu = p.nu; a.D = p.D;
-  a.buoy_rho0 = 0.0;
   a.TH = p.TH;
   a.uw_multi = 2.0 * p.rho0 * p.uw / cs2 / p.CFL;  // LBM.cu:1896-1898 without the weight
+  a.rhs = p.n_lattices > 1 ? work : nullptr;
+  a.rhs_scale = -p.convertCtoCharge / p.eps;
+  a.rhs_wall_lo = -p.voltage / p.dz / p.dz;
+  a.rhs_wall_hi = -p.voltage2 / p.dz / p.dz;
   return a;
 }
 
@@ -282,6 +285,7 @@ extern "C" int ekpnp_bind_field(ekpnp_ctx* ctx, int id, double* dptr) {
   if (c.fld_owned[id]) { (void)hipFree(c.fld[id]); c.bytes -= c.nloc * sizeof(double); }
   c.fld[id] = dptr;
   c.fld_owned[id] = false;
+  c.rhs_ready = false;
   return EKPNP_OK;
 }
 
@@ -297,6 +301,7 @@ extern "C" int ekpnp_set_field(ekpnp_ctx* ctx, int id, const double* host) {
   if (id < 0 || id >= EKPNP_NFIELDS || !host) return fail(c, "bad field id or NULL pointer");
   HIPCHK(c, hipStreamSynchronize(c.stream));
   HIPCHK(c, hipMemcpy(c.fld[id], host, c.nloc * sizeof(double), hipMemcpyHostToDevice));
+  c.rhs_ready = false;
   return EKPNP_OK;
 }
 
@@ -333,7 +338,8 @@ extern "C" size_t ekpnp_device_bytes(const ekpnp_ctx* ctx) { return ctx ? ctx->c
 // Poisson
 
 static int poisson_single(Ctx& c) {
-  launch_poisson_rhs(c);
+  if (!c.rhs_ready) launch_poisson_rhs(c);
+  c.rhs_ready = false;  // the inverse transform overwrites work[]
   FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.work, (hipfftDoubleComplex*)c.spec));
   launch_tridiag(c);
   FFTCHK(c, hipfftExecZ2D(c.plan_inv, (hipfftDoubleComplex*)c.spec, c.work));
@@ -353,6 +359,7 @@ extern "C" int ekpnp_fast_poisson(ekpnp_ctx* ctx) {
 
 extern "C" int ekpnp_init_fields(ekpnp_ctx* ctx) {  // gpu_initialization, LBM.cu:111-128
   NEEDCTX(ctx);
+  c.rhs_ready = false;
   launch_init_fields(c);
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;
@@ -367,6 +374,7 @@ extern "C" int ekpnp_pbe_begin(ekpnp_ctx* ctx) {  // LBM.cu:79-86: phi_old <- ph
 
 extern "C" int ekpnp_pbe_concentrations(ekpnp_ctx* ctx) {  // gpu_PBE, LBM.cu:139-146
   NEEDCTX(ctx);
+  c.rhs_ready = false;
   launch_pbe(c);
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;
@@ -393,6 +401,7 @@ extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
   int rc = ekpnp_init_fields(ctx);
   if (rc == EKPNP_OK) rc = ekpnp_pbe_begin(ctx);
   for (int i = 0; rc == EKPNP_OK && i < c.p.pb_iterations; ++i) {  // LBM.cu:89-106
+    c.rhs_ready = false;
     launch_pbe(c);
     rc = poisson_single(c);
     launch_pbe_relax(c, c.phi_old);
@@ -450,6 +459,7 @@ static int collide_range(Ctx& c, int zb, int ze, bool timed) {
 static void finish_collide(Ctx& c) {
   c.cur ^= 1;
   c.streamed_state = false;
+  c.rhs_ready = c.p.n_lattices > 1;  // every owned plane has written its Poisson rhs into work[]
 }
 
 extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
@@ -576,7 +586,8 @@ extern "C" int ekpnp_advance_time(ekpnp_ctx* ctx) {
 extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_fast_poisson");
-  launch_poisson_rhs(c);
+  if (!c.rhs_ready) launch_poisson_rhs(c);
+  c.rhs_ready = false;
   FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.work, (hipfftDoubleComplex*)c.spec));
   launch_slab_thomas_local(c);
   HIPCHK(c, hipGetLastError());

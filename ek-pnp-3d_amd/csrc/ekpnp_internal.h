@@ -59,9 +59,13 @@ struct KArgs {
   double mob[MAXL];            // drift mobility: 0, K, Kn, 0
   double sp, sm;               // 1 - dt*omega/2
   double cflinv, inv_cs2, cflinv2, dt;
-  double F, Ext, exf, buoy_rho0, Ra, nu, D;
+  double F, Ext, exf, Ra, nu, D;
   double TH, uw_multi;         // uw_multi = 2*rho0*uw/cs_square/CFL (times w_d in the kernel)
   double rho0;
+  // Poisson right-hand side written by the collide itself (poisson.cu:114-135 fused in)
+  double* rhs;                 // [nzl][ny][nx] or null
+  double rhs_scale;            // -F/eps
+  double rhs_wall_lo, rhs_wall_hi;  // -voltage/dz^2 (plane 1), -voltage2/dz^2 (plane nz-2)
 };
 
 struct PArgs {
@@ -110,6 +114,7 @@ struct Ctx {
   bool own_stream = false;
   double* pop[2][MAXL] = {};   // [buffer][lattice]
   int cur = 0;                 // buffer holding the current state
+  bool rhs_ready = false;      // work[] holds the Poisson rhs of the current c, cn (written by the collide)
   bool streamed_state = true;  // true: pop[cur] holds X1 (post-stream, e.g. fresh equilibrium);
                                // false: pop[cur] holds post-collision populations (pull next)
   double* fld[EKPNP_NFIELDS] = {};

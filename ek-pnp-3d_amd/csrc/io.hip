@@ -159,5 +159,6 @@ extern "C" int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time) {
   HIPCHK(c, hipStreamSynchronize(c.stream));
   for (int i = 0; i < EKPNP_NFIELDS; ++i) HIPCHK(c, hipMemcpy(c.fld[i], h[i].data(), c.nloc * sizeof(double), hipMemcpyHostToDevice));
   c.t = *time;
+  c.rhs_ready = false;
   return EKPNP_OK;
 }

@@ -242,6 +242,13 @@ __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(
   } else {
     const double m = lat == 1 ? c : lat == 2 ? cn : T;
     if (act) a.fld[lat == 1 ? EKPNP_C : lat == 2 ? EKPNP_CN : EKPNP_T][sidx] = m;  // LBM.cu:811-813
+    if (lat == 1 && act && a.rhs) {  // odd_extension's interior rows, poisson.cu:121-135, from registers
+      const int z = a.z0 + zl;
+      double g = a.rhs_scale * (c - cn);
+      if (z == 1) g = g + a.rhs_wall_lo;
+      if (z == a.nz - 2) g = g + a.rhs_wall_hi;
+      a.rhs[sidx] = g;
+    }
     const double k = a.mob[lat];
     collide_scalar(a, f, m, ux + k * Ex, uy + k * Ey, uz + k * Ez, a.wp[lat], a.wm[lat], store);
   }
@@ -361,6 +368,7 @@ __global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int to
     a.fld[EKPNP_CN][sidx] = ms[1];
   }
   if constexpr (NL > 3) a.fld[EKPNP_T][sidx] = ms[2];
+  if (a.rhs) a.rhs[sidx] = 0.0;  // wall planes carry no Poisson unknown (poisson.cu:116-119,136-139)
 
   // fluid: gpu_boundary (LBM.cu:1848-1961) discards the wall collision: f0 <- pre-collision f0,
   // f2[d] <- pre-collision f1[opp d] (+ moving-wall terms on the upper plate).

@@ -192,8 +192,19 @@ def main():
     else:
         from ek_pnp_3d_amd.slab import DistributedSlab  # noqa: WPS433
 
-        runner = DistributedSlab(p, rank, world, dist)
-        sol = runner.solver
+        # a rank that cannot build its slab (e.g. out of memory) must not leave the others
+        # waiting in a collective: agree on success before anybody enters the exchange
+        err = None
+        try:
+            runner = DistributedSlab(p, rank, world, dist)
+            sol = runner.solver
+        except Exception as e:  # noqa: BLE001
+            err = e
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            dist.destroy_process_group()
+            raise SystemExit(f"rank {rank}: slab creation failed on at least one rank: {err}")
 
     # untimed start-up (the reference's timer also starts after it, main.cu:161-186)
     if nz_global > 128 and nl > 1:

@@ -222,6 +222,66 @@ def test_mass_conservation_and_symmetry_at_scale(pkg, O):
         assert np.abs(f[k] - prof).max() <= 1e-9 * scale, k
 
 
+def test_cfg2_full_size_properties(pkg, O):
+    """BASELINE cfg2 at its full size (256^3, f + h + hn): size-independent properties.
+    (i) phi returned by fast_Poisson satisfies the discrete equation the reference solves
+    (spectral in x,y: checked through its 2-D FFT; second-order FD in z, Dirichlet walls,
+    poisson.cu:114-180); (ii) E is the central difference of phi bit for bit; (iii) total fluid
+    mass and total ion count of the interior-to-interior exchange stay finite and mass is
+    conserved; (iv) linearity of the Poisson solve in (c - cn)."""
+    n = 256
+    p = pkg.default_params(n, n, n)
+    p.n_lattices, p.Ra = 3, 0.0
+    rng = np.random.default_rng(2)
+    with pkg.Solver(p) as s:
+        c = 0.01 * (1 + 0.05 * rng.random(s.shape))
+        cn = 0.01 * (1 + 0.05 * rng.random(s.shape))
+        s.set_field("c", c); s.set_field("cn", cn)
+        s.fast_Poisson()
+        phi, ex, ey, ez = (s.get_field(k) for k in ("phi", "Ex", "Ey", "Ez"))
+        # (ii)
+        assert np.array_equal(ex, 0.5 * (np.roll(phi, 1, 2) - np.roll(phi, -1, 2)) / p.dx)
+        assert np.array_equal(ey, 0.5 * (np.roll(phi, 1, 1) - np.roll(phi, -1, 1)) / p.dy)
+        ezr = 0.5 * (np.roll(phi, 1, 0) - np.roll(phi, -1, 0)) / p.dz
+        ezr[0], ezr[-1] = ezr[1], ezr[-2]
+        assert np.array_equal(ez, ezr)
+        assert np.all(phi[0] == p.voltage) and np.all(phi[-1] == p.voltage2)
+        # (i) residual of  d2z phi - (kx^2 + ky^2) phi = -F (c - cn)/eps  in (kx, ky, z) space
+        ph = np.fft.rfft2(phi, axes=(1, 2))
+        g = np.fft.rfft2(-p.convertCtoCharge * (c - cn) / p.eps, axes=(1, 2))
+        kx = 2 * np.pi * np.arange(n // 2 + 1) / p.Lx
+        ky = 2 * np.pi * np.fft.fftfreq(n, d=1.0 / n) / p.Ly
+        k2 = ky[:, None] ** 2 + kx[None, :] ** 2
+        lhs = (ph[:-2] - 2 * ph[1:-1] + ph[2:]) / p.dz**2 - k2[None] * ph[1:-1]
+        res = np.abs(lhs - g[1:-1]).max() / np.abs(g[1:-1]).max()
+        assert res < 1e-9, res
+        del ph, g, lhs
+        # (iv)
+        s.set_field("c", 2 * c - cn * 0); s.set_field("cn", 2 * cn)
+        s.fast_Poisson()
+        phi2 = s.get_field("phi")
+        # phi = phi_walls + L(c - cn): doubling the charge doubles the deviation from the zero-charge solution
+        s.set_field("c", np.zeros(s.shape)); s.set_field("cn", np.zeros(s.shape))
+        s.fast_Poisson()
+        phi0 = s.get_field("phi")
+        assert np.abs((phi2 - phi0) - 2 * (phi - phi0)).max() < 1e-12 * np.abs(phi - phi0).max()
+        del phi2, phi0
+    # (iii) a short run from the Gouy-Chapman start of the bench
+    import bench
+
+    with pkg.Solver(p) as s:
+        bench.gouy_chapman_state(s, p)
+        bench.apply_perturbation(s, None, p)
+        s.fast_Poisson(); s.init_equilibrium()
+        s.step(1)
+        m0 = s.get_field("rho").sum()
+        s.step(20)
+        f = s.fields()
+        assert all(np.isfinite(v).all() for v in f.values())
+        assert abs(f["rho"].sum() / m0 - 1) < 1e-12
+        assert f["c"].min() > 0 and f["cn"].min() > 0
+
+
 # ---- golden vectors produced by the reference's own kernels --------------------------------
 # The HIP path returns the exact (DC = 0) Poisson solution, the reference's run carries its FFT
 # library's DC-mode leak (tests/test_oracle_cpu.py pins the oracle to the reference WITH the

@@ -120,7 +120,6 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
   const int zl1 = min(zl0 + PHI_ZCHUNK, a.nzl);
   const int xp1 = x + 1 == a.nx ? 0 : x + 1, xm1 = x == 0 ? a.nx - 1 : x - 1;
   const int yp1 = y + 1 == a.ny ? 0 : y + 1, ym1 = y == 0 ? a.ny - 1 : y - 1;
-  const double hx = 0.5 / a.dx, hy = 0.5 / a.dy, hz = 0.5 / a.dz;
   double pm = phi_at(a, x, y, a.z0 + zl0 - 1);
   double p0 = phi_at(a, x, y, a.z0 + zl0);
   for (int zl = zl0; zl < zl1; ++zl) {
@@ -128,12 +127,14 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
     const double pp = phi_at(a, x, y, z + 1);
     const long long i = ((long long)zl * a.ny + y) * a.nx + x;
     a.fld[EKPNP_PHI][i] = p0;
-    a.fld[EKPNP_EX][i] = (phi_at(a, xm1, y, z) - phi_at(a, xp1, y, z)) * hx;
-    a.fld[EKPNP_EY][i] = (phi_at(a, x, ym1, z) - phi_at(a, x, yp1, z)) * hy;
+    // the reference's expression 0.5*(a - b)/d (poisson.cu:53-55), kept so that E is the same
+    // bits as a central difference of the returned phi
+    a.fld[EKPNP_EX][i] = 0.5 * (phi_at(a, xm1, y, z) - phi_at(a, xp1, y, z)) / a.dx;
+    a.fld[EKPNP_EY][i] = 0.5 * (phi_at(a, x, ym1, z) - phi_at(a, x, yp1, z)) / a.dy;
     double ez;
-    if (z == 0) ez = (p0 - phi_at(a, x, y, 2)) * hz;                          // gpu_bc: Ez(0) <- Ez(1)
-    else if (z == a.nz - 1) ez = (phi_at(a, x, y, a.nz - 3) - p0) * hz;        // gpu_bc: Ez(NZ-1) <- Ez(NZ-2)
-    else ez = (pm - pp) * hz;
+    if (z == 0) ez = 0.5 * (p0 - phi_at(a, x, y, 2)) / a.dz;                    // gpu_bc: Ez(0) <- Ez(1)
+    else if (z == a.nz - 1) ez = 0.5 * (phi_at(a, x, y, a.nz - 3) - p0) / a.dz;  // gpu_bc: Ez(NZ-1) <- Ez(NZ-2)
+    else ez = 0.5 * (pm - pp) / a.dz;
     a.fld[EKPNP_EZ][i] = ez;
     pm = p0;
     p0 = pp;

@@ -282,6 +282,39 @@ def test_cfg2_full_size_properties(pkg, O):
         assert f["c"].min() > 0 and f["cn"].min() > 0
 
 
+def test_cfg3_maximum_size_translation_invariance(pkg, O):
+    """BASELINE cfg3 at full size: 512^3 nodes x 4 lattices = 247 GB, population indices beyond
+    2^32 (the reference's `unsigned int` index arithmetic, LBM.cu:27-30, overflows above 165 M
+    nodes).  Size-independent property: an x-y uniform problem does not know NX, NY, so the z
+    profiles of the 512x512x512 run must equal those of a 64x64x512 run (only the FFT sizes, i.e.
+    rounding, differ)."""
+    import torch
+
+    import bench
+
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 252e9:
+        pytest.skip("needs 247 GB of free HBM")
+    prof = {}
+    for n in (64, 512):
+        p = pkg.default_params(n, n, 512)
+        with pkg.Solver(p) as s:
+            bench.gouy_chapman_state(s, p)
+            s.fast_Poisson()
+            s.init_equilibrium()
+            s.step(4)
+            prof[n] = {k: s.get_field(k) for k in ("rho", "c", "cn", "phi", "T", "Ez", "uz")}
+            if n == 512:
+                assert s.device_bytes() > 245e9
+                for k, v in prof[n].items():  # x-y uniform at the far corner of the index space too
+                    assert np.abs(v[:, -1, -1] - v[:, 0, 0]).max() <= 1e-12 * np.abs(v).max(), k
+            prof[n] = {k: v[:, 0, 0].copy() for k, v in prof[n].items()}
+    for k in prof[64]:
+        a, b = prof[512][k], prof[64][k]
+        tol = 1e-7 if k == "uz" else 1e-11
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (k, np.abs(a - b).max(), np.abs(b).max())
+
+
 # ---- golden vectors produced by the reference's own kernels --------------------------------
 # The HIP path returns the exact (DC = 0) Poisson solution, the reference's run carries its FFT
 # library's DC-mode leak (tests/test_oracle_cpu.py pins the oracle to the reference WITH the

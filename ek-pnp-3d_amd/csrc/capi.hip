@@ -383,7 +383,7 @@ extern "C" int ekpnp_pbe_concentrations(ekpnp_ctx* ctx) {  // gpu_PBE, LBM.cu:13
 extern "C" int ekpnp_pbe_relax(ekpnp_ctx* ctx) {  // gpu_PBE_phi + phi_old update, LBM.cu:98-104
   NEEDCTX(ctx);
   if (!c.phi_old) return fail(c, "ekpnp_pbe_relax without ekpnp_pbe_begin");
-  launch_pbe_relax(c, c.phi_old);
+  launch_pbe_relax(c, c.phi_old, c.p.PB_omega);
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;
 }
@@ -404,11 +404,61 @@ extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
     c.rhs_ready = false;
     launch_pbe(c);
     rc = poisson_single(c);
-    launch_pbe_relax(c, c.phi_old);
+    launch_pbe_relax(c, c.phi_old, c.p.PB_omega);
   }
   int rc2 = ekpnp_pbe_end(ctx);
   if (rc == EKPNP_OK) rc = rc2;
   if (rc == EKPNP_OK) HIPCHK(c, hipGetLastError());
+  return rc;
+}
+
+// the same Picard sweeps as initialization() (LBM.cu:89-106), but
+//  - stopped by a convergence test instead of the fixed 501 sweeps: the residual is
+//    max |phi_solved - phi_old| / max(|voltage|, |voltage2|), reduced on the device;
+//  - with a damping that cannot diverge: the lowest z mode of the linearised iteration is
+//    amplified by A = (Lz/(pi lambda_D))^2 per sweep, so PB_omega = 0.05 diverges once A > 39
+//    (NZ > ~180 at the default spacing); omega = min(PB_omega, 1.6/(1 + A)) is used.
+extern "C" int ekpnp_initialization_converged(ekpnp_ctx* ctx, double rel_tol, int max_sweeps, int* sweeps, double* residual) {
+  NEEDCTX(ctx);
+  if (c.nranks != 1) return fail(c, "ekpnp_initialization_converged is implemented for single-slab contexts");
+  if (max_sweeps < 0) return fail(c, "max_sweeps < 0");
+  double omega = c.p.PB_omega;
+  if (c.p.chargeinf > 0.0) {
+    const double lam2 = c.p.eps * c.p.kB * c.p.roomT / c.p.electron / (2.0 * c.p.chargeinf * c.p.convertCtoCharge);
+    const double A = c.p.Lz * c.p.Lz / (M_PI * M_PI * lam2);
+    if (1.6 / (1.0 + A) < omega) omega = 1.6 / (1.0 + A);
+  }
+  double scale = std::fabs(c.p.voltage) > std::fabs(c.p.voltage2) ? std::fabs(c.p.voltage) : std::fabs(c.p.voltage2);
+  if (scale == 0.0) scale = 1.0;
+  if (!c.diag) HIPCHK(c, hipMalloc((void**)&c.diag, DIAG_SCRATCH * sizeof(double)));
+  int rc = ekpnp_init_fields(ctx);
+  if (rc == EKPNP_OK) rc = ekpnp_pbe_begin(ctx);
+  int done = 0;
+  double res = 0.0;
+  const int check_every = 10;
+  while (rc == EKPNP_OK && done < max_sweeps) {
+    c.rhs_ready = false;
+    launch_pbe(c);
+    rc = poisson_single(c);
+    if (rc) break;
+    ++done;
+    const bool check = (done % check_every == 0) || done == max_sweeps;
+    if (check) launch_max_abs_diff(c, c.fld[EKPNP_PHI], c.phi_old, c.diag);
+    launch_pbe_relax(c, c.phi_old, omega);
+    if (check) {
+      double r = 0.0;
+      hipError_t e = hipMemcpyAsync(&r, c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+      if (e != hipSuccess) { c.err = "residual read-back failed"; rc = EKPNP_ERR_HIP; break; }
+      res = r / scale;
+      if (!(res == res)) { c.err = "Poisson-Boltzmann iteration produced NaN"; rc = EKPNP_ERR_INVALID; break; }
+      if (res <= rel_tol) break;
+    }
+  }
+  int rc2 = ekpnp_pbe_end(ctx);
+  if (rc == EKPNP_OK) rc = rc2;
+  if (sweeps) *sweeps = done;
+  if (residual) *residual = res;
   return rc;
 }
 

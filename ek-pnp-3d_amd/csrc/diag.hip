@@ -60,6 +60,16 @@ __global__ void __launch_bounds__(256) k_max_uz(const double* __restrict__ uz, l
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+// max |a - b| (Picard residual of the Poisson-Boltzmann start)
+__global__ void __launch_bounds__(256) k_max_abs_diff(const double* __restrict__ p, const double* __restrict__ q, long long n,
+                                                      double* __restrict__ partial) {
+  __shared__ double lds[4];
+  double m = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmax(m, fabs(p[i] - q[i]));
+  const double r = block_reduce<true>(m, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
 template <bool IS_MAX>
 __global__ void __launch_bounds__(256) k_final(const double* __restrict__ partial, int n, double* __restrict__ out) {
   __shared__ double lds[4];
@@ -82,6 +92,13 @@ void launch_umax(Ctx& c, double* scratch) {
   const long long n = (long long)c.nloc;
   const int nb = (int)((n + 255) / 256 < DIAG_BLOCKS ? (n + 255) / 256 : DIAG_BLOCKS);
   hipLaunchKernelGGL(k_max_uz, dim3(nb), dim3(256), 0, c.stream, c.fld[EKPNP_UZ], n, scratch);
+  hipLaunchKernelGGL((k_final<true>), dim3(1), dim3(256), 0, c.stream, scratch, nb, scratch + DIAG_BLOCKS);
+}
+
+void launch_max_abs_diff(Ctx& c, const double* p, const double* q, double* scratch) {
+  const long long n = (long long)c.nloc;
+  const int nb = (int)((n + 255) / 256 < DIAG_BLOCKS ? (n + 255) / 256 : DIAG_BLOCKS);
+  hipLaunchKernelGGL(k_max_abs_diff, dim3(nb), dim3(256), 0, c.stream, p, q, n, scratch);
   hipLaunchKernelGGL((k_final<true>), dim3(1), dim3(256), 0, c.stream, scratch, nb, scratch + DIAG_BLOCKS);
 }
 

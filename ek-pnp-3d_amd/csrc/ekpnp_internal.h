@@ -85,7 +85,7 @@ struct Ctx;
 // lbm_kernels.hip
 void launch_init_fields(Ctx&);
 void launch_pbe(Ctx&);
-void launch_pbe_relax(Ctx&, double* phi_old);
+void launch_pbe_relax(Ctx&, double* phi_old, double omega);
 void launch_init_equilibrium(Ctx&);
 void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
 void launch_collide_walls(Ctx&);
@@ -104,6 +104,7 @@ void launch_phi_halo_pack(Ctx&);
 constexpr int DIAG_SCRATCH = 1024 + 8;
 void launch_current(Ctx&, double* scratch);
 void launch_umax(Ctx&, double* scratch);
+void launch_max_abs_diff(Ctx&, const double* p, const double* q, double* scratch);
 
 struct Ctx {
   ekpnp_params p{};

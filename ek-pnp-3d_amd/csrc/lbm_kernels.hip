@@ -519,9 +519,9 @@ void launch_pbe(Ctx& c) {
                      (long long)c.nloc, c.p.chargeinf, c.p.electron, c.p.kB, c.p.roomT);
 }
 
-void launch_pbe_relax(Ctx& c, double* phi_old) {
+void launch_pbe_relax(Ctx& c, double* phi_old, double omega) {
   hipLaunchKernelGGL(k_pbe_relax, grid1d((long long)c.nloc, 256), dim3(256), 0, c.stream, c.fld[EKPNP_PHI], phi_old, (long long)c.nloc,
-                     c.p.PB_omega);
+                     omega);
 }
 
 void launch_init_equilibrium(Ctx& c) {

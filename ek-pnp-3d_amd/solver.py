@@ -99,6 +99,7 @@ def load_library():
         "ekpnp_set_field": (i32, [ctx, i32, C.c_void_p]),
         "ekpnp_get_field": (i32, [ctx, i32, C.c_void_p]),
         "ekpnp_initialization": (i32, [ctx]),
+        "ekpnp_initialization_converged": (i32, [ctx, dbl, i32, C.POINTER(i32), pd]),
         "ekpnp_init_equilibrium": (i32, [ctx]),
         "ekpnp_stream_collide_save": (i32, [ctx, dbl]),
         "ekpnp_fast_poisson": (i32, [ctx]),
@@ -237,6 +238,12 @@ class Solver:
     # -- the reference's host API (LBM.h:159-180) ---------------------------------------------
     def initialization(self):
         self._ck(self._L.ekpnp_initialization(self._h))
+
+    def initialization_converged(self, rel_tol: float = 1e-10, max_sweeps: int = 100000):
+        """initialization() with a convergence test; returns (sweeps done, relative residual)."""
+        n, r = C.c_int(), C.c_double()
+        self._ck(self._L.ekpnp_initialization_converged(self._h, float(rel_tol), int(max_sweeps), C.byref(n), C.byref(r)))
+        return n.value, r.value
 
     def init_equilibrium(self):
         self._ck(self._L.ekpnp_init_equilibrium(self._h))

@@ -126,6 +126,14 @@ int ekpnp_get_field(ekpnp_ctx* ctx, int field_id, double* host);
  * uniform fields + pb_iterations Poisson-Boltzmann sweeps, all on the device. */
 int ekpnp_initialization(ekpnp_ctx* ctx);
 
+/* initialization() with a convergence test instead of the fixed sweep count (SURVEY.md §8(f)
+ * row 4; LBM.cu:89-106): stops when max|phi_solved - phi_old| <= rel_tol * max(|voltage|,
+ * |voltage2|) or after max_sweeps; damping omega = min(PB_omega, 1.6/(1 + (Lz/(pi lambda_D))^2)),
+ * which equals the reference's PB_omega on its own grid and does not diverge on tall channels
+ * (the reference's 0.05 does beyond NZ ~ 180).  rel_tol = 0 and max_sweeps = pb_iterations
+ * reproduce ekpnp_initialization bit for bit wherever the damping is not reduced. */
+int ekpnp_initialization_converged(ekpnp_ctx* ctx, double rel_tol, int max_sweeps, int* sweeps_done, double* residual);
+
 /* void init_equilibrium(f0,f1,h0,h1,hn0,hn1,temp0,temp1,r,c,cn,u,v,w,ex,ey,ez,temp)
  * — LBM.h:162-163, LBM.cu:150-160: populations <- equilibrium of the fields. */
 int ekpnp_init_equilibrium(ekpnp_ctx* ctx);

@@ -108,3 +108,41 @@ def test_io_errors_are_returned(pkg, tmp_path):
             s.read_data(str(tmp_path / "short.dat"))
         with pytest.raises(pkg.EkpnpError):
             s.save_data_end(str(tmp_path / "no_such_dir" / "x.dat"), 0.0)
+
+
+# ---- §8(f) row 4: PB initialisation with a convergence test ---------------------------------
+
+def test_initialization_converged_matches_fixed_sweeps_on_the_reference_grid(pkg, O):
+    po = O.default_params(50, 8, 51)
+    po.Lx, po.Ly, po.Lz = 0.5e-6, 0.08e-6, 0.5e-6
+    p = _mirror(pkg, po)
+    with pkg.Solver(p) as a, pkg.Solver(p) as b:
+        a.initialization()
+        n, res = b.initialization_converged(rel_tol=0.0, max_sweeps=501)
+        assert n == 501 and res < 1e-6
+        for k in ("phi", "c", "cn", "Ez", "T", "rho"):
+            assert np.array_equal(a.get_field(k), b.get_field(k)), k
+        n2, res2 = b.initialization_converged(rel_tol=1e-9, max_sweeps=20000)
+        assert res2 <= 1e-9 and n2 > 501
+        c, cn = b.get_field("c"), b.get_field("cn")
+        assert np.allclose(c * cn, po.chargeinf**2, rtol=1e-12)
+
+
+def test_initialization_converged_on_a_tall_channel_where_the_reference_diverges(pkg, O):
+    """NZ = 256: (Lz/(pi lambda_D))^2 = 78, the reference's PB_omega = 0.05 diverges (NaN)."""
+    p = pkg.default_params(16, 8, 256)
+    with pkg.Solver(p) as s:
+        s.initialization()
+        assert not np.isfinite(s.get_field("phi")).all()  # the reference's own start-up blows up here
+        n, res = s.initialization_converged(rel_tol=1e-8, max_sweeps=50000)
+        f = s.fields()
+        assert res <= 1e-8 and all(np.isfinite(v).all() for v in f.values())
+        assert np.allclose(f["c"] * f["cn"], p.chargeinf**2, rtol=1e-10)
+        mid = f["phi"][128, 0, 0]
+        assert abs(mid) < 1e-6 * abs(p.voltage)  # double layers far apart: neutral core
+        # Gouy-Chapman at the wall: tanh(e phi/4kT) = tanh(e zeta/4kT) exp(-z/lambda_D), lattice value within 2 %
+        lam = np.sqrt(p.eps * p.kB * p.roomT / p.electron / (2 * p.chargeinf * p.convertCtoCharge))
+        vt = p.kB * p.roomT / p.electron
+        z = 5 * p.dz
+        gc = 4 * vt * np.arctanh(np.tanh(p.voltage / (4 * vt)) * np.exp(-z / lam))
+        assert abs(f["phi"][5, 0, 0] - gc) < 0.02 * abs(gc)

@@ -123,7 +123,8 @@ def test_initialization_converged_matches_fixed_sweeps_on_the_reference_grid(pkg
         for k in ("phi", "c", "cn", "Ez", "T", "rho"):
             assert np.array_equal(a.get_field(k), b.get_field(k)), k
         n2, res2 = b.initialization_converged(rel_tol=1e-9, max_sweeps=20000)
-        assert res2 <= 1e-9 and n2 > 501
+        assert res2 <= 1e-9 and n2 < 501  # 320 sweeps: the fixed 501 of LBM.cu:89 over-iterate
+        assert np.abs(b.get_field("phi") - a.get_field("phi")).max() < 1e-8 * abs(po.voltage)
         c, cn = b.get_field("c"), b.get_field("cn")
         assert np.allclose(c * cn, po.chargeinf**2, rtol=1e-12)
 

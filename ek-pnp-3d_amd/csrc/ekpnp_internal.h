@@ -88,7 +88,7 @@ void launch_pbe(Ctx&);
 void launch_pbe_relax(Ctx&, double* phi_old, double omega);
 void launch_init_equilibrium(Ctx&);
 void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
-void launch_collide_walls(Ctx&);
+void launch_collide_walls(Ctx&, hipStream_t stream);
 void launch_ghost_wrap(Ctx&);
 void launch_halo_pack(Ctx&, int buffer);
 void launch_halo_unpack(Ctx&);
@@ -113,6 +113,8 @@ struct Ctx {
   size_t plane = 0, nloc = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t aux = nullptr;        // second stream: the wall planes run beside the bulk kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double* pop[2][MAXL] = {};   // [buffer][lattice]
   int cur = 0;                 // buffer holding the current state
   bool rhs_ready = false;      // work[] holds the Poisson rhs of the current c, cn (written by the collide)

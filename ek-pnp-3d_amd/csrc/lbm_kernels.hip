@@ -562,23 +562,23 @@ void launch_collide_bulk(Ctx& c, int zl_begin, int zl_end) {
 }
 
 template <int NL>
-static void wall_dispatch(Ctx& c, const KArgs& a, int top) {
+static void wall_dispatch(Ctx& c, const KArgs& a, int top, hipStream_t stream) {
   dim3 g((unsigned)((c.p.nx + 63) / 64), (unsigned)c.p.ny), b(64);
   if (c.streamed_state)
-    hipLaunchKernelGGL((k_collide_wall<NL, false>), g, b, 0, c.stream, a, top);
+    hipLaunchKernelGGL((k_collide_wall<NL, false>), g, b, 0, stream, a, top);
   else
-    hipLaunchKernelGGL((k_collide_wall<NL, true>), g, b, 0, c.stream, a, top);
+    hipLaunchKernelGGL((k_collide_wall<NL, true>), g, b, 0, stream, a, top);
 }
 
-void launch_collide_walls(Ctx& c) {
+void launch_collide_walls(Ctx& c, hipStream_t stream) {
   KArgs a = c.kargs();
   for (int top = 0; top < 2; ++top) {
     const bool owns = top ? (c.z0 + c.nzl == c.p.nz) : (c.z0 == 0);
     if (!owns) continue;
     switch (c.p.n_lattices) {
-      case 1: wall_dispatch<1>(c, a, top); break;
-      case 3: wall_dispatch<3>(c, a, top); break;
-      default: wall_dispatch<4>(c, a, top); break;
+      case 1: wall_dispatch<1>(c, a, top, stream); break;
+      case 3: wall_dispatch<3>(c, a, top, stream); break;
+      default: wall_dispatch<4>(c, a, top, stream); break;
     }
   }
 }

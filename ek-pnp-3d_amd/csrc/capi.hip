@@ -162,7 +162,10 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   c.rank = rank; c.nranks = nranks;
   c.nzl = p->nz / nranks;
   c.z0 = rank * c.nzl;
-  c.nxh = p->nx / 2 + 1;
+  // row pitch of the half spectrum: NX/2+1 complex, padded to a multiple of 8 (128 bytes) so that
+  // rocFFT's strided y pass and the mode-parallel z sweeps work on aligned rows; the pad columns
+  // are zero and stay zero (the transforms never touch them, the z solve maps 0 to 0)
+  c.nxh = (p->nx / 2 + 1 + 7) / 8 * 8;
   c.plane = (size_t)p->nx * p->ny;
   c.nloc = c.plane * c.nzl;
   auto bail = [&](int code) {
@@ -192,6 +195,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   }
   if ((rc = dev_alloc(c, (void**)&c.work, c.nloc * sizeof(double)))) return bail(rc);
   if ((rc = dev_alloc(c, (void**)&c.spec, (size_t)c.nzl * p->ny * c.nxh * sizeof(double2)))) return bail(rc);
+  if (hipMemsetAsync(c.spec, 0, (size_t)c.nzl * p->ny * c.nxh * sizeof(double2), c.stream) != hipSuccess) { c.err = "hipMemsetAsync failed"; return bail(EKPNP_ERR_HIP); }
   const size_t nmodes = (size_t)p->ny * c.nxh;
   const size_t cprime_rows = nranks == 1 ? (size_t)p->nz : (size_t)c.nzl + 2;
   if ((rc = dev_alloc(c, (void**)&c.cprime, cprime_rows * nmodes * sizeof(double)))) return bail(rc);
@@ -217,8 +221,10 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   // batched 2-D real transforms over the owned planes (replaces cufftPlan3d, main.cu:112)
   {
     int n[2] = {p->ny, p->nx};
-    hipfftResult r = hipfftPlanMany(&c.plan_fwd, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, c.nzl);
-    if (r == HIPFFT_SUCCESS) r = hipfftPlanMany(&c.plan_inv, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, c.nzl);
+    int rembed[2] = {p->ny, p->nx};      // real planes, dense
+    int cembed[2] = {p->ny, c.nxh};      // half spectrum with the padded row pitch
+    hipfftResult r = hipfftPlanMany(&c.plan_fwd, 2, n, rembed, 1, p->ny * p->nx, cembed, 1, p->ny * c.nxh, HIPFFT_D2Z, c.nzl);
+    if (r == HIPFFT_SUCCESS) r = hipfftPlanMany(&c.plan_inv, 2, n, cembed, 1, p->ny * c.nxh, rembed, 1, p->ny * p->nx, HIPFFT_Z2D, c.nzl);
     if (r != HIPFFT_SUCCESS) { c.err = "hipfftPlanMany failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
     c.plans = true;
     hipfftSetStream(c.plan_fwd, c.stream);

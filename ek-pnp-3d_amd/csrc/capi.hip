@@ -178,12 +178,6 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
     return bail(EKPNP_ERR_HIP);
   }
   c.own_stream = true;
-  if (hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming) != hipSuccess) {
-    c.err = "auxiliary stream/event creation failed";
-    return bail(EKPNP_ERR_HIP);
-  }
   const size_t popbytes = (size_t)Q * (c.nzl + 2) * c.plane * sizeof(double);
   for (int b = 0; b < 2; ++b)
     for (int l = 0; l < p->n_lattices; ++l)
@@ -265,9 +259,6 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   }
   if (c.plans) { hipfftDestroy(c.plan_fwd); hipfftDestroy(c.plan_inv); }
   for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  if (c.aux) { (void)hipStreamSynchronize(c.aux); (void)hipStreamDestroy(c.aux); }
-  if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
-  if (c.ev_join) (void)hipEventDestroy(c.ev_join);
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
   delete ctx;
   return EKPNP_OK;
@@ -531,15 +522,11 @@ extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
   NEEDCTX(ctx);
   (void)t;  // the reference passes t but never uses it (LBM.cu:483-1846)
   if (c.nranks != 1) return fail(c, "slab context: use ekpnp_collide_boundary_planes/interior_planes + halo transport");
-  // the two wall planes (latency-bound, 0.4 % of the nodes) run on the auxiliary stream beside
-  // the bandwidth-bound bulk kernel: both read buffer A and write disjoint planes of buffer B
-  HIPCHK(c, hipEventRecord(c.ev_fork, c.stream));
-  HIPCHK(c, hipStreamWaitEvent(c.aux, c.ev_fork, 0));
-  launch_collide_walls(c, c.aux);
-  HIPCHK(c, hipEventRecord(c.ev_join, c.aux));
+  // (running the two wall planes on a second stream beside the bulk kernel was measured: no gain,
+  // the bulk kernel already saturates HBM and merely stretches - profiles/r01_bench_after_tuning.log)
   int rc = collide_range(c, bulk_begin(c), bulk_end(c), true);
   if (rc) return rc;
-  HIPCHK(c, hipStreamWaitEvent(c.stream, c.ev_join, 0));
+  launch_collide_walls(c, c.stream);
   finish_collide(c);
   launch_ghost_wrap(c);  // z-periodic ghost loop of gpu_stream, LBM.cu:1972,1975
   HIPCHK(c, hipGetLastError());

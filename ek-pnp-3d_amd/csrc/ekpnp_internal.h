@@ -113,8 +113,6 @@ struct Ctx {
   size_t plane = 0, nloc = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t aux = nullptr;        // second stream: the wall planes run beside the bulk kernel
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double* pop[2][MAXL] = {};   // [buffer][lattice]
   int cur = 0;                 // buffer holding the current state
   bool rhs_ready = false;      // work[] holds the Poisson rhs of the current c, cn (written by the collide)

@@ -97,19 +97,17 @@ __device__ __forceinline__ double phi_at(const PArgs& a, int x, int y, int z /*g
   return a.work[((long long)zl * a.ny + y) * a.nx + x] * a.inv_nxny;
 }
 
-constexpr int PHI_ZCHUNK = 8;
+constexpr int PHI_ZCHUNK = 16;
 
-// One thread owns a column of PHI_ZCHUNK planes: all of its loads (the column itself plus the
-// x+-1 / y+-1 neighbours of every plane) are issued before the first store, so a wave keeps
-// ~40 loads in flight; every phi value is read from HBM once for its three z uses (the
-// neighbours come from the same or the adjacent row, i.e. from cache).
+// One thread marches up a column of PHI_ZCHUNK planes with phi(z-1), phi(z), phi(z+1) in
+// registers: every phi value is read once for the three z uses (the x+-1 / y+-1 neighbours come
+// from the same or the adjacent row, i.e. from cache).
 //
 // XCD-aware placement as in k_collide_bulk: the (y, z-chunk) rows are dealt to the 8 XCDs in
 // runs of 64 consecutive y, so the y+-1 neighbour rows are found in the XCD's own L2 (with rows
 // dealt one by one every L2 fetched all three rows: 4.1 GB fetched for 1.07 GB of phi).
 __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, const int nrows) {
   constexpr int RCHUNK = 64;
-  constexpr int ZC = PHI_ZCHUNK;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int r = slot / nxb, xb = slot - r * nxb;
@@ -118,39 +116,28 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
   const int x = xb * blockDim.x + threadIdx.x;
   if (x >= a.nx) return;
   const int y = row % a.ny;
-  const int zl0 = (row / a.ny) * ZC;
+  const int zl0 = (row / a.ny) * PHI_ZCHUNK;
+  const int zl1 = min(zl0 + PHI_ZCHUNK, a.nzl);
   const int xp1 = x + 1 == a.nx ? 0 : x + 1, xm1 = x == 0 ? a.nx - 1 : x - 1;
   const int yp1 = y + 1 == a.ny ? 0 : y + 1, ym1 = y == 0 ? a.ny - 1 : y - 1;
-  double col[ZC + 2], nxm[ZC], nxp[ZC], nym[ZC], nyp[ZC];
-#pragma unroll
-  for (int k = 0; k < ZC + 2; ++k) col[k] = phi_at(a, x, y, a.z0 + zl0 + k - 1);
-#pragma unroll
-  for (int k = 0; k < ZC; ++k) {
-    const int z = a.z0 + zl0 + k;
-    nxm[k] = phi_at(a, xm1, y, z);
-    nxp[k] = phi_at(a, xp1, y, z);
-    nym[k] = phi_at(a, x, ym1, z);
-    nyp[k] = phi_at(a, x, yp1, z);
-  }
-  // wall planes: gpu_bc copies the neighbouring interior plane's Ez (poisson.cu:57-69)
-  const double ez_lo = (a.z0 + zl0 == 0) ? 0.5 * (col[1] - phi_at(a, x, y, 2)) / a.dz : 0.0;
-  const double ez_hi = (a.z0 + zl0 + ZC >= a.nz) ? 0.5 * (phi_at(a, x, y, a.nz - 3) - a.voltage2) / a.dz : 0.0;
-#pragma unroll
-  for (int k = 0; k < ZC; ++k) {
-    const int zl = zl0 + k;
-    if (zl < a.nzl) {
-      const int z = a.z0 + zl;
-      const long long i = ((long long)zl * a.ny + y) * a.nx + x;
-      // the reference's expression 0.5*(a - b)/d (poisson.cu:53-55), kept so that E is the same
-      // bits as a central difference of the returned phi
-      a.fld[EKPNP_PHI][i] = col[k + 1];
-      a.fld[EKPNP_EX][i] = 0.5 * (nxm[k] - nxp[k]) / a.dx;
-      a.fld[EKPNP_EY][i] = 0.5 * (nym[k] - nyp[k]) / a.dy;
-      double ez = 0.5 * (col[k] - col[k + 2]) / a.dz;
-      if (z == 0) ez = ez_lo;
-      if (z == a.nz - 1) ez = ez_hi;
-      a.fld[EKPNP_EZ][i] = ez;
-    }
+  double pm = phi_at(a, x, y, a.z0 + zl0 - 1);
+  double p0 = phi_at(a, x, y, a.z0 + zl0);
+  for (int zl = zl0; zl < zl1; ++zl) {
+    const int z = a.z0 + zl;
+    const double pp = phi_at(a, x, y, z + 1);
+    const long long i = ((long long)zl * a.ny + y) * a.nx + x;
+    a.fld[EKPNP_PHI][i] = p0;
+    // the reference's expression 0.5*(a - b)/d (poisson.cu:53-55), kept so that E is the same
+    // bits as a central difference of the returned phi
+    a.fld[EKPNP_EX][i] = 0.5 * (phi_at(a, xm1, y, z) - phi_at(a, xp1, y, z)) / a.dx;
+    a.fld[EKPNP_EY][i] = 0.5 * (phi_at(a, x, ym1, z) - phi_at(a, x, yp1, z)) / a.dy;
+    double ez;
+    if (z == 0) ez = 0.5 * (p0 - phi_at(a, x, y, 2)) / a.dz;                    // gpu_bc: Ez(0) <- Ez(1)
+    else if (z == a.nz - 1) ez = 0.5 * (phi_at(a, x, y, a.nz - 3) - p0) / a.dz;  // gpu_bc: Ez(NZ-1) <- Ez(NZ-2)
+    else ez = 0.5 * (pm - pp) / a.dz;
+    a.fld[EKPNP_EZ][i] = ez;
+    pm = p0;
+    p0 = pp;
   }
 }
 

@@ -97,7 +97,10 @@ __device__ __forceinline__ double phi_at(const PArgs& a, int x, int y, int z /*g
   return a.work[((long long)zl * a.ny + y) * a.nx + x] * a.inv_nxny;
 }
 
-constexpr int PHI_ZCHUNK = 16;
+#ifndef EKPNP_PHI_ZCHUNK
+#define EKPNP_PHI_ZCHUNK 16  // tuning knob: planes marched per thread
+#endif
+constexpr int PHI_ZCHUNK = EKPNP_PHI_ZCHUNK;
 
 // One thread marches up a column of PHI_ZCHUNK planes with phi(z-1), phi(z), phi(z+1) in
 // registers: every phi value is read once for the three z uses (the x+-1 / y+-1 neighbours come

@@ -1,0 +1,147 @@
+// ekpnp_main.cpp — thin C++ host over the C ABI that keeps main.cu's driver / IO surface.
+//
+// Same sequence as main.cu:19-296 of the reference: parameters -> banner -> (read previous data |
+// initialization) -> init_equilibrium -> first Tecplot zone -> time loop {stream_collide_save;
+// fast_Poisson; t += dt; every NSAVE steps a Tecplot zone; every printCurrent steps the wall
+// current and a umax line} -> performance banner -> last zone -> data_end.dat.  Same file names
+// (data.dat, umax.dat, data_end.dat), same cadence (i % NSAVE == 1, i % printCurrent == 1,
+// main.cu:206,211), same text formats (the writers are in io.hip).
+//
+// What is different on purpose: the grid, the step count and the physics knobs are run-time
+// options instead of compile-time constants (LBM.h:29-125); the "read previous data" question
+// is a flag instead of scanf (main.cu:158-159); no system("pause") (main.cu:294); errors are
+// reported and returned, not exit()ed from inside the library.  Only the C ABI of
+// include/ekpnp.h is used: this file is also the worked example of INTEGRATION.md.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/ekpnp.h"
+
+static int fail(ekpnp_ctx* ctx, const char* what, int rc) {
+  std::fprintf(stderr, "ekpnp_main: %s failed (%d): %s\n", what, rc, ekpnp_last_error(ctx));
+  if (ctx) ekpnp_destroy(ctx);
+  return 1;
+}
+#define CK(call)                              \
+  do {                                        \
+    int rc_ = (call);                         \
+    if (rc_ != EKPNP_OK) return fail(ctx, #call, rc_); \
+  } while (0)
+
+int main(int argc, char* argv[]) {
+  // LBM.h:32-35,122-125
+  int nx = 50, ny = 8, nz = 51;
+  unsigned nsteps = 1000, nsave = 0, print_current = 50;
+  int flag = 0;  // 1: read previous data (main.cu:161)
+  int lattices = 4;
+  std::string out = ".";
+  double exf = 0.0, uw = 0.0, chargeinf = -1.0, Ra = -1.0, TH = -1.0;
+  for (int i = 1; i < argc; ++i) {
+    auto val = [&](const char* name) -> const char* {
+      if (std::strcmp(argv[i], name) == 0 && i + 1 < argc) return argv[++i];
+      return nullptr;
+    };
+    const char* v;
+    if ((v = val("--nx"))) nx = std::atoi(v);
+    else if ((v = val("--ny"))) ny = std::atoi(v);
+    else if ((v = val("--nz"))) nz = std::atoi(v);
+    else if ((v = val("--steps"))) nsteps = (unsigned)std::atoi(v);
+    else if ((v = val("--nsave"))) nsave = (unsigned)std::atoi(v);
+    else if ((v = val("--print-current"))) print_current = (unsigned)std::atoi(v);
+    else if ((v = val("--read-previous"))) flag = std::atoi(v);
+    else if ((v = val("--lattices"))) lattices = std::atoi(v);
+    else if ((v = val("--out"))) out = v;
+    else if ((v = val("--exf"))) exf = std::atof(v);
+    else if ((v = val("--uw"))) uw = std::atof(v);
+    else if ((v = val("--chargeinf"))) chargeinf = std::atof(v);
+    else if ((v = val("--Ra"))) Ra = std::atof(v);
+    else if ((v = val("--TH"))) TH = std::atof(v);
+    else {
+      std::fprintf(stderr,
+                   "usage: ekpnp_main [--nx N --ny N --nz N] [--steps N] [--nsave N] [--print-current N] [--read-previous 0|1]\n"
+                   "                  [--lattices 1|3|4] [--exf F --uw U --chargeinf C --Ra R --TH T] [--out DIR]\n");
+      return 2;
+    }
+  }
+  if (nsave == 0) nsave = nsteps / 2 ? nsteps / 2 : 1;  // LBM.h:123
+  if (print_current == 0) print_current = 1;
+
+  ekpnp_ctx* ctx = nullptr;
+  ekpnp_params P;
+  if (ekpnp_default_params(&P, nx, ny, nz) != EKPNP_OK) return fail(nullptr, "ekpnp_default_params", 1);
+  if (nx == 50 && ny == 8 && nz == 51) { P.Lx = 0.5e-6; P.Ly = 0.08e-6; P.Lz = 0.5e-6; }  // literals of LBM.h:40-42
+  P.n_lattices = lattices;
+  P.exf = exf; P.uw = uw;  // main.cu:30-31
+  if (chargeinf >= 0.0) P.chargeinf = chargeinf;
+  if (Ra >= 0.0) P.Ra = Ra;
+  if (TH >= 0.0) P.TH = TH;
+
+  // main.cu:40-52
+  std::printf("Simulating 3D electrokinetic flow with heat transfer vortices\n");
+  std::printf("      domain size (NX x NY x NZ): %ux%ux%u\n", (unsigned)nx, (unsigned)ny, (unsigned)nz);
+  std::printf("               Ra: %g\n", P.Ra);
+  std::printf("               Pr: %g\n", P.nu / P.D);  // compute_parameters, LBM.cu:2445
+  std::printf("            uwall: %g\n", P.uw);
+  std::printf("   External force: %g\n", P.exf);
+  std::printf("        timesteps: %u\n", nsteps);
+  std::printf("       save every: %u\n", nsave);
+  std::printf("    message every: %u\n", nsave);
+  std::printf("\n");
+
+  {
+    int rc = ekpnp_create(&P, &ctx);
+    if (rc != EKPNP_OK) return fail(nullptr, "ekpnp_create", rc);
+  }
+  std::printf("HIP information\n");
+  std::printf("      device memory held by the solver: %.1f MiB\n\n", (double)ekpnp_device_bytes(ctx) / (1024.0 * 1024.0));
+
+  const std::string f_data = out + "/data.dat", f_umax = out + "/umax.dat", f_end = out + "/data_end.dat";
+  double t = 0.0;
+  if (flag == 1) {  // main.cu:161-164
+    std::printf("Reading previous data...\n");
+    CK(ekpnp_read_data(ctx, f_end.c_str(), &t));
+  } else {  // main.cu:165-171
+    std::printf("Initializing...\n");
+    CK(ekpnp_initialization(ctx));
+    t = 0.0;
+  }
+  CK(ekpnp_set_time(ctx, t));
+  CK(ekpnp_init_equilibrium(ctx));                             // main.cu:174
+  CK(ekpnp_save_data_tecplot(ctx, f_data.c_str(), 0, t, 1));   // main.cu:178-179 ("wb+")
+  { FILE* f = std::fopen(f_umax.c_str(), "wb"); if (f) std::fclose(f); }  // main.cu:180
+
+  CK(ekpnp_synchronize(ctx));
+  const auto begin = std::chrono::steady_clock::now();  // main.cu:185-186
+  for (unsigned i = 0; i < nsteps; i++) {               // main.cu:189-224
+    CK(ekpnp_stream_collide_save(ctx, t));
+    CK(ekpnp_fast_poisson(ctx));
+    t = t + P.dt;
+    if (i % nsave == 1) {
+      CK(ekpnp_save_data_tecplot(ctx, f_data.c_str(), 1, t, 1));
+      std::printf("Iteration: %u, physical time: %g.\n", i, t);
+    }
+    if (i % print_current == 1) {
+      double I = 0.0;
+      CK(ekpnp_current(ctx, &I));  // reduced on the device (main.cu:212-215 copies 3 fields to the host)
+      std::printf("Iteration: %u, physical time: %g, Current = %g\n", i, t, I);
+      CK(ekpnp_record_umax(ctx, f_umax.c_str(), 1, t));
+    }
+  }
+  CK(ekpnp_synchronize(ctx));
+  const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count();
+
+  // main.cu:241-251
+  const double nodes_updated = (double)nsteps * (double)nx * (double)ny * (double)nz;
+  std::printf(" ----- performance information -----\n");
+  std::printf("               timesteps: %u\n", nsteps);
+  std::printf("           clock runtime: %.3f (s)\n", runtime);
+  std::printf("                   speed: %.2f (Mlups)\n", nodes_updated / (1e6 * runtime));
+
+  CK(ekpnp_save_data_tecplot(ctx, f_data.c_str(), 1, t, 1));  // main.cu:253
+  CK(ekpnp_save_data_end(ctx, f_end.c_str(), 0, t));          // main.cu:256-257
+  CK(ekpnp_destroy(ctx));                                     // main.cu:264-290
+  return 0;
+}

@@ -147,3 +147,50 @@ def test_initialization_converged_on_a_tall_channel_where_the_reference_diverges
         z = 5 * p.dz
         gc = 4 * vt * np.arctanh(np.tanh(p.voltage / (4 * vt)) * np.exp(-z / lam))
         assert abs(f["phi"][5, 0, 0] - gc) < 0.02 * abs(gc)
+
+
+# ---- the C++ host that keeps main.cu's driver / IO surface -------------------------------------
+
+def test_cpp_driver_reproduces_the_library_calls(pkg, O, tmp_path):
+    """ek-pnp-3d_amd/ekpnp_main (csrc/ekpnp_main.cpp) runs main.cu's sequence over the C ABI; its
+    files must be byte-identical to the same sequence driven through the ctypes mirror."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "ek-pnp-3d_amd", "ekpnp_main")
+    if not os.path.exists(exe):
+        pytest.skip("ekpnp_main not built")
+    shape, steps, nsave, pc = (16, 8, 17), 60, 20, 10
+    out = tmp_path / "cpp"
+    out.mkdir()
+    r = subprocess.run([exe, "--nx", str(shape[0]), "--ny", str(shape[1]), "--nz", str(shape[2]), "--steps", str(steps), "--nsave", str(nsave),
+                        "--print-current", str(pc), "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "speed:" in r.stdout and r.stdout.count("Current = ") == steps // pc
+    p = pkg.default_params(*shape)
+    ref = tmp_path / "py"
+    ref.mkdir()
+    currents = []
+    with pkg.Solver(p) as s:
+        s.initialization(); s.init_equilibrium()
+        t = 0.0
+        s.save_data_tecplot(str(ref / "data.dat"), t, first=True, append=False)
+        open(ref / "umax.dat", "wb").close()
+        for i in range(steps):  # main.cu:189-224
+            s.stream_collide_save(t); s.fast_Poisson(); t = t + p.dt
+            if i % nsave == 1:
+                s.save_data_tecplot(str(ref / "data.dat"), t, first=True, append=True)
+            if i % pc == 1:
+                currents.append(s.current())
+                s.record_umax(str(ref / "umax.dat"), t, append=True)
+        s.save_data_tecplot(str(ref / "data.dat"), t, first=True, append=True)
+        s.save_data_end(str(ref / "data_end.dat"), t)
+    for name in ("data.dat", "umax.dat", "data_end.dat"):
+        assert _sha(str(out / name)) == _sha(str(ref / name)), name
+    printed = [float(l.split("Current = ")[1]) for l in r.stdout.splitlines() if "Current = " in l]
+    assert np.allclose(printed, currents, rtol=1e-5)  # %g prints 6 significant digits
+    # restart: main.cu:161-164 (flag == 1) reads data_end.dat back
+    r2 = subprocess.run([exe, "--nx", str(shape[0]), "--ny", str(shape[1]), "--nz", str(shape[2]), "--steps", "2", "--read-previous", "1",
+                         "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and "Reading previous data" in r2.stdout, r2.stderr
+    r3 = subprocess.run([exe, "--nx", "8", "--ny", "8", "--nz", "2"], capture_output=True, text=True, timeout=60)
+    assert r3.returncode != 0 and "failed" in r3.stderr  # errors are reported, never a crash

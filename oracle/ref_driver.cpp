@@ -20,6 +20,7 @@
  *            upload 11 fields, fast_Poisson, init_equilibrium, steps; dumps <tag>_step0.bin,
  *            <tag>_step<n>.bin and <tag>_step_trace.bin ([1+steps][2][NZ])
  *        ref_driver <outdir> poisson <in.bin> <tag>     -> upload fields, one fast_Poisson, dump
+ *        ref_driver <outdir> time <nsteps>              -> wall time of the reference's own step
  *        ref_driver <outdir> io <in.bin> <tag>          -> upload fields; the reference's own
  *            save_data_tecplot (2 zones), save_data_end, record_umax and current() on them
  *        --set name=value writes a __constant__/__device__ physics symbol of LBM.h at run time
@@ -38,6 +39,8 @@
 #include "LBM.cu"
 #include "poisson.cu"
 
+#include <chrono>
+static double seconds_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static double* g_fields[11];
 static const char* g_names[11] = {"rho", "c", "cn", "phi", "ux", "uy", "uz", "Ex", "Ey", "Ez", "T"};
 
@@ -271,6 +274,25 @@ int main(int argc, char** argv) {
     fwrite(&cur, sizeof(double), 1, g);
     fclose(g);
     printf("wrote %s io files, current = %.17g\n", tag.c_str(), cur);
+  } else if (mode == "time" && args.size() >= 2) {
+    /* throughput of the reference's own step (main.cu:189-200, no IO) on this GPU */
+    const int n = atoi(args[1].c_str());
+    initialization(rho_gpu, charge_gpu, chargen_gpu, phi_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
+    init_equilibrium(f0_gpu, f1_gpu, h0_gpu, h1_gpu, hn0_gpu, hn1_gpu, temp0_gpu, temp1_gpu, rho_gpu, charge_gpu, chargen_gpu, ux_gpu,
+                     uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
+    auto step = [&]() {
+      stream_collide_save(f0_gpu, f1_gpu, f2_gpu, h0_gpu, h1_gpu, h2_gpu, hn0_gpu, hn1_gpu, hn2_gpu, temp0_gpu, temp1_gpu, temp2_gpu,
+                          rho_gpu, charge_gpu, chargen_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu, t, f0bc);
+      fast_Poisson(charge_gpu, chargen_gpu, kx, ky, kz, plan);
+    };
+    for (int i = 0; i < 20; ++i) step();
+    checkCudaErrors(hipDeviceSynchronize());
+    const double t0 = seconds_now();
+    for (int i = 0; i < n; ++i) step();
+    checkCudaErrors(hipDeviceSynchronize());
+    const double dtw = seconds_now() - t0;
+    printf("reference step on this GPU: %d steps of %ux%ux%u in %.4f s = %.3f ms/step = %.2f MLUPS\n", n, NX, NY, NZ, dtw, 1e3 * dtw / n,
+           (double)n * NX * NY * NZ / dtw / 1e6);
   } else if (mode == "poisson" && args.size() >= 3) {
     upload(args[1].c_str());
     fast_Poisson(charge_gpu, chargen_gpu, kx, ky, kz, plan);

@@ -4,6 +4,7 @@
 // (LBM.cu:68-109,150-160,465-481; poisson.cu:75-103).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -38,6 +39,11 @@ static thread_local std::string g_create_err;
 static int fail(Ctx& c, const char* msg) {
   c.err = msg;
   return EKPNP_ERR_INVALID;
+}
+
+static void drop_graph(Ctx& c) {
+  if (c.graph2) { (void)hipGraphExecDestroy(c.graph2); c.graph2 = nullptr; }
+  c.graph_cur = -1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -246,6 +252,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (c.work) (void)hipFree(c.work);
   if (c.spec) (void)hipFree(c.spec);
   if (c.cprime) (void)hipFree(c.cprime);
+  drop_graph(c);
   if (c.slab_u) (void)hipFree(c.slab_u);
   if (c.u1um[0]) (void)hipFree(c.u1um[0]);
   if (c.u1um[1]) (void)hipFree(c.u1um[1]);
@@ -270,6 +277,7 @@ extern "C" int ekpnp_set_stream(ekpnp_ctx* ctx, void* s) {
   NEEDCTX(ctx);
   HIPCHK(c, hipStreamSynchronize(c.stream));
   if (c.own_stream) { (void)hipStreamDestroy(c.stream); c.own_stream = false; }
+  drop_graph(c);
   c.stream = (hipStream_t)s;
   FFTCHK(c, hipfftSetStream(c.plan_fwd, c.stream));
   FFTCHK(c, hipfftSetStream(c.plan_inv, c.stream));
@@ -292,6 +300,7 @@ extern "C" int ekpnp_bind_field(ekpnp_ctx* ctx, int id, double* dptr) {
   c.fld[id] = dptr;
   c.fld_owned[id] = false;
   c.rhs_ready = false;
+  drop_graph(c);
   return EKPNP_OK;
 }
 
@@ -533,15 +542,78 @@ extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
   return EKPNP_OK;
 }
 
+static int one_step(ekpnp_ctx* ctx) {  // main.cu:189-200
+  Ctx& c = ctx->c;
+  int rc = ekpnp_stream_collide_save(ctx, c.t);
+  if (rc) return rc;
+  rc = poisson_single(c);
+  if (rc) return rc;
+  c.t = c.t + c.p.dt;
+  return EKPNP_OK;
+}
+
+// Small lattices are launch-bound (the reference's own 50x8x51 problem: ~10 launches of a few
+// microseconds each per step).  Two consecutive steps (buffers A->B, then B->A) are captured once
+// into a hipGraph and replayed; the arithmetic and its order are exactly the eager ones.
+static bool graph_wanted(const Ctx& c, int nsteps) {
+  static const bool off = std::getenv("EKPNP_NO_GRAPH") != nullptr;
+  return !off && !c.graph_failed && !c.timing && !c.streamed_state && nsteps >= 4 && c.nranks == 1 &&
+         c.nloc <= (size_t)4 * 1024 * 1024;  // beyond ~4 M nodes a step is >1 ms of kernels: nothing to gain
+}
+
+static int capture_two_steps(ekpnp_ctx* ctx) {
+  Ctx& c = ctx->c;
+  drop_graph(c);
+  const int cur0 = c.cur;
+  const double t0 = c.t;
+  if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); c.graph_failed = true; return EKPNP_OK; }
+  int rc = one_step(ctx);
+  if (rc == EKPNP_OK) rc = one_step(ctx);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(c.stream, &g);
+  // nothing has executed: restore the host-side state the two calls advanced
+  c.cur = cur0;
+  c.t = t0;
+  c.rhs_ready = false;
+  if (rc != EKPNP_OK || e != hipSuccess || !g) {
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    c.graph_failed = true;
+    c.err.clear();
+    return EKPNP_OK;
+  }
+  e = hipGraphInstantiate(&c.graph2, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) { (void)hipGetLastError(); c.graph2 = nullptr; c.graph_failed = true; return EKPNP_OK; }
+  c.graph_cur = cur0;
+  return EKPNP_OK;
+}
+
 extern "C" int ekpnp_step(ekpnp_ctx* ctx, int nsteps) {
   NEEDCTX(ctx);
   if (nsteps < 0) return fail(c, "nsteps < 0");
-  for (int i = 0; i < nsteps; ++i) {  // main.cu:189-200
-    int rc = ekpnp_stream_collide_save(ctx, c.t);
+  if (c.nranks != 1) return fail(c, "slab context: drive the split calls through the slab host");
+  int i = 0;
+  if (c.streamed_state && nsteps > 0) {  // the first step after init_equilibrium does not pull
+    int rc = one_step(ctx);
     if (rc) return rc;
-    rc = poisson_single(c);
+    ++i;
+  }
+  if (graph_wanted(c, nsteps - i)) {
+    if (!c.graph2 || c.graph_cur != c.cur) {
+      int rc = capture_two_steps(ctx);
+      if (rc) return rc;
+    }
+    while (c.graph2 && nsteps - i >= 2) {
+      HIPCHK(c, hipGraphLaunch(c.graph2, c.stream));
+      c.t = c.t + c.p.dt;
+      c.t = c.t + c.p.dt;
+      i += 2;
+    }
+  }
+  for (; i < nsteps; ++i) {
+    int rc = one_step(ctx);
     if (rc) return rc;
-    c.t = c.t + c.p.dt;
   }
   return EKPNP_OK;
 }

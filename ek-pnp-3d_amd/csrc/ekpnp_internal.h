@@ -135,6 +135,10 @@ struct Ctx {
   double* phi_old = nullptr;       // PB relaxation state (ekpnp_pbe_begin/end)
   double* diag = nullptr;          // reduction scratch (DIAG_SCRATCH doubles)
   int collide_phase = 0;           // 0 idle, 1 boundary planes done
+  // hipGraph of two consecutive steps (A->B, B->A) for launch-bound lattices
+  hipGraphExec_t graph2 = nullptr;
+  int graph_cur = -1;              // value of `cur` the graph was captured at
+  bool graph_failed = false;       // capture is not possible here: stay eager
   hipfftHandle plan_fwd = 0, plan_inv = 0;
   bool plans = false;
   double t = 0.0;

@@ -379,3 +379,29 @@ def test_golden_G2_hip_first_step_moments_vs_reference(pkg, O):
     err = O.rel_l2(f, {k: g["step1_" + k] for k in f}, {k: [k] for k in f})
     _REPORT.append({"test": "golden_G2_step1_moments", "mark": "1", "rel_l2": err})
     assert max(err.values()) < 1e-13, err
+
+
+def test_graph_replay_is_bitwise_the_eager_path(pkg, O, monkeypatch):
+    """ekpnp_step replays a captured 2-step hipGraph on launch-bound lattices; the results must be
+    the eager ones bit for bit, for even and odd step counts and across re-captures."""
+    po = O.default_params(24, 8, 13)
+    po.pb_iterations = 10
+    p = _mirror(pkg, po)
+    outs = []
+    for mode in ("graph", "eager"):
+        with pkg.Solver(p) as s:
+            s.initialization()
+            s.set_fields(O.perturb_fields(po, s.fields()))
+            s.fast_Poisson(); s.init_equilibrium()
+            if mode == "graph":
+                s.step(11); s.step(8); s.stream_collide_save(); s.fast_Poisson(); s.step(7)
+            else:
+                for _ in range(11 + 8):
+                    s.stream_collide_save(); s.fast_Poisson()
+                s.stream_collide_save(); s.fast_Poisson()
+                for _ in range(7):
+                    s.stream_collide_save(); s.fast_Poisson()
+            outs.append((s.fields(), s.t))
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+    assert abs(outs[0][1] - 26 * p.dt) < 1e-22

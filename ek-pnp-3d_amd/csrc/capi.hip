@@ -348,6 +348,7 @@ extern "C" int ekpnp_set_time(ekpnp_ctx* ctx, double t) {
 }
 
 extern "C" size_t ekpnp_device_bytes(const ekpnp_ctx* ctx) { return ctx ? ctx->c.bytes : 0; }
+extern "C" int ekpnp_graph_state(const ekpnp_ctx* ctx) { return !ctx ? 0 : ctx->c.graph_failed ? -1 : ctx->c.graph2 ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------
 // Poisson

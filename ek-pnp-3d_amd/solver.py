@@ -110,6 +110,7 @@ def load_library():
         "ekpnp_kernel_timing_enable": (i32, [ctx, i32]),
         "ekpnp_kernel_timing_get": (i32, [ctx, C.POINTER(i32), pd, C.POINTER(C.c_int64)]),
         "ekpnp_device_bytes": (sz, [ctx]),
+        "ekpnp_graph_state": (i32, [ctx]),
         "ekpnp_halo_buffer": (i32, [ctx, i32, C.POINTER(C.c_void_p), C.POINTER(sz)]),
         "ekpnp_halo_pack": (i32, [ctx]),
         "ekpnp_halo_unpack": (i32, [ctx]),
@@ -206,6 +207,9 @@ class Solver:
 
     def set_stream(self, hip_stream: int):
         self._ck(self._L.ekpnp_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def graph_state(self) -> int:
+        return int(self._L.ekpnp_graph_state(self._h))
 
     def device_bytes(self) -> int:
         return int(self._L.ekpnp_device_bytes(self._h))

@@ -182,6 +182,8 @@ int ekpnp_kernel_timing_enable(ekpnp_ctx* ctx, int enable);
 int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* total_ms,
                             int64_t* nodes_per_launch);
 size_t ekpnp_device_bytes(const ekpnp_ctx* ctx);
+/* 1: ekpnp_step holds an instantiated 2-step hipGraph, 0: none yet, -1: capture failed (eager). */
+int ekpnp_graph_state(const ekpnp_ctx* ctx);
 
 /* ---- z-slab halo interface (no reference counterpart) ------- */
 /* The populations a neighbour needs after a collide: the 9 c_z=+1 directions of

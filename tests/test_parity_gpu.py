@@ -394,7 +394,9 @@ def test_graph_replay_is_bitwise_the_eager_path(pkg, O, monkeypatch):
             s.set_fields(O.perturb_fields(po, s.fields()))
             s.fast_Poisson(); s.init_equilibrium()
             if mode == "graph":
-                s.step(11); s.step(8); s.stream_collide_save(); s.fast_Poisson(); s.step(7)
+                s.step(11)
+                assert s.graph_state() == 1, "the 2-step graph was not captured"
+                s.step(8); s.stream_collide_save(); s.fast_Poisson(); s.step(7)
             else:
                 for _ in range(11 + 8):
                     s.stream_collide_save(); s.fast_Poisson()

@@ -25,7 +25,7 @@ def _single(pkg, O, p, start, steps):
         return init, st, s.fields()
 
 
-@pytest.mark.parametrize("shape,nslabs", [((16, 12, 16), 2), ((20, 6, 24), 3), ((70, 5, 32), 4), ((16, 8, 64), 8)])
+@pytest.mark.parametrize("shape,nslabs", [((16, 12, 16), 2), ((20, 6, 24), 3), ((70, 5, 32), 4), ((16, 8, 64), 8), ((12, 6, 40), 2), ((10, 4, 16), 4), ((8, 4, 102), 3)])
 def test_local_slab_group_equals_single_context(pkg, O, shape, nslabs):
     from ek_pnp_3d_amd.slab import LocalSlabGroup
 

@@ -20,6 +20,8 @@
  *            upload 11 fields, fast_Poisson, init_equilibrium, steps; dumps <tag>_step0.bin,
  *            <tag>_step<n>.bin and <tag>_step_trace.bin ([1+steps][2][NZ])
  *        ref_driver <outdir> poisson <in.bin> <tag>     -> upload fields, one fast_Poisson, dump
+ *        ref_driver <outdir> kernels <in.bin> <tag>     -> G4: populations after init_equilibrium, one
+ *            full step, then after each of gpu_collide_save / gpu_boundary / gpu_stream / gpu_bc_charge
  *        ref_driver <outdir> time <nsteps>              -> wall time of the reference's own step
  *        ref_driver <outdir> io <in.bin> <tag>          -> upload fields; the reference's own
  *            save_data_tecplot (2 zones), save_data_end, record_umax and current() on them
@@ -118,6 +120,31 @@ static void traced_initialization() {
   }
   free(phi_old_host);
   checkCudaErrors(hipFree(phi_old_gpu));
+}
+
+/* populations of the four lattices on the y rows {0,3,5}: X0 then X1 (which == 1) or X2 (which == 2),
+ * each as [27][NZ][3][NX] with d = 0 the rest population */
+static void dump_pops(const std::string& path, int which) {
+  const unsigned ys[3] = {0, 3, 5};
+  double* x0[4] = {f0_gpu, h0_gpu, hn0_gpu, temp0_gpu};
+  double* x1[4] = {f1_gpu, h1_gpu, hn1_gpu, temp1_gpu};
+  double* x2[4] = {f2_gpu, h2_gpu, hn2_gpu, temp2_gpu};
+  std::vector<double> h0((size_t)NX * NY * NZ), hn((size_t)NX * NY * NZ * 26), o;
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+  for (int l = 0; l < 4; ++l) {
+    CHECK(hipMemcpy(h0.data(), x0[l], mem_size_0dir, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hn.data(), which == 1 ? x1[l] : x2[l], mem_size_n0dir, hipMemcpyDeviceToHost));
+    o.clear();
+    for (unsigned d = 0; d < 27; ++d)
+      for (unsigned z = 0; z < NZ; ++z)
+        for (unsigned k = 0; k < 3; ++k)
+          for (unsigned x = 0; x < NX; ++x)
+            o.push_back(d == 0 ? h0[scalar_index(x, ys[k], z)] : hn[(size_t)NX * (NY * (NZ * (d - 1) + z) + ys[k]) + x]);
+    fwrite(o.data(), sizeof(double), o.size(), f);
+  }
+  fclose(f);
+  printf("wrote %s\n", path.c_str());
 }
 
 static std::vector<double> snapshot() {
@@ -274,6 +301,32 @@ int main(int argc, char** argv) {
     fwrite(&cur, sizeof(double), 1, g);
     fclose(g);
     printf("wrote %s io files, current = %.17g\n", tag.c_str(), cur);
+  } else if (mode == "kernels" && args.size() >= 3) {
+    /* per-kernel vectors: the four launches of stream_collide_save
+     * (LBM.cu:474-477) one by one, populations dumped after each */
+    upload(args[1].c_str());
+    std::string tag = args[2];
+    fast_Poisson(charge_gpu, chargen_gpu, kx, ky, kz, plan);
+    dump(out + "/" + tag + "_fields0.bin");
+    init_equilibrium(f0_gpu, f1_gpu, h0_gpu, h1_gpu, hn0_gpu, hn1_gpu, temp0_gpu, temp1_gpu, rho_gpu, charge_gpu, chargen_gpu, ux_gpu,
+                     uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
+    dump_pops(out + "/" + tag + "_eq.bin", 1);
+    /* one full step first, so that the vectors are not those of a pure equilibrium */
+    stream_collide_save(f0_gpu, f1_gpu, f2_gpu, h0_gpu, h1_gpu, h2_gpu, hn0_gpu, hn1_gpu, hn2_gpu, temp0_gpu, temp1_gpu, temp2_gpu,
+                        rho_gpu, charge_gpu, chargen_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu, t, f0bc);
+    dump_pops(out + "/" + tag + "_step1.bin", 1);
+    dim3 grid(NX / nThreads, NY, NZ);
+    dim3 threads(nThreads, 1, 1);
+    gpu_collide_save<<<grid, threads>>>(f0_gpu, f1_gpu, f2_gpu, h0_gpu, h1_gpu, h2_gpu, hn0_gpu, hn1_gpu, hn2_gpu, temp0_gpu, temp1_gpu,
+                                        temp2_gpu, rho_gpu, charge_gpu, chargen_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu, t, f0bc);
+    dump_pops(out + "/" + tag + "_collide.bin", 2);
+    dump(out + "/" + tag + "_fields_collide.bin");
+    gpu_boundary<<<grid, threads>>>(f0_gpu, f1_gpu, f2_gpu, h0_gpu, h1_gpu, h2_gpu, hn0_gpu, hn1_gpu, hn2_gpu, temp0_gpu, temp1_gpu, temp2_gpu, f0bc);
+    dump_pops(out + "/" + tag + "_boundary.bin", 2);
+    gpu_stream<<<grid, threads>>>(f0_gpu, f1_gpu, f2_gpu, h0_gpu, h1_gpu, h2_gpu, hn0_gpu, hn1_gpu, hn2_gpu, temp0_gpu, temp1_gpu, temp2_gpu);
+    dump_pops(out + "/" + tag + "_stream.bin", 1);
+    gpu_bc_charge<<<grid, threads>>>(h0_gpu, h1_gpu, h2_gpu, hn0_gpu, hn1_gpu, hn2_gpu, temp0_gpu, temp1_gpu, temp2_gpu);
+    dump_pops(out + "/" + tag + "_bc_charge.bin", 1);
   } else if (mode == "time" && args.size() >= 2) {
     /* throughput of the reference's own step (main.cu:189-200, no IO) on this GPU */
     const int n = atoi(args[1].c_str());

@@ -108,6 +108,21 @@ def main(outdir):
     g2["step_trace"] = trace(os.path.join(tmp, "g2_step_trace.bin"), 51)
     np.savez_compressed(os.path.join(outdir, "ref_g2_full.npz"), **g2)
 
+    # ---- G4: per-kernel vectors on the G2 input (populations on the y rows {0,3,5})
+    run("kernels", inp, "g4")
+    npop = 4 * 27 * NZ * 3 * NX
+    g4 = {}
+    for stage in ("step1", "collide", "boundary", "stream", "bc_charge"):
+        a = np.fromfile(os.path.join(tmp, f"g4_{stage}.bin"), dtype=np.float64)
+        assert a.size == npop, (stage, a.size)
+        g4[stage] = a.reshape(4, 27, NZ, 3, NX)
+    f0 = read_bin(os.path.join(tmp, "g4_fields0.bin"))
+    fc = read_bin(os.path.join(tmp, "g4_fields_collide.bin"))
+    for k in O.FIELDS:
+        g4["fields0_" + k] = f0[k]
+        g4["fields_collide_" + k] = fc[k]
+    np.savez_compressed(os.path.join(outdir, "ref_g4_full.npz"), **g4)
+
     # ---- G3: body-force driven channel (Poiseuille), no ions, no buoyancy: rho and u do not
     # depend on phi at all here (force = F (c - cn) E = 0), so they are free of the DC leak.
     run("--set", "exf=1e9", "--set", "chargeinf=0", "--set", "Ra=0", "--set", "TH=0", "init", "g3", "1", "100", "3000")

@@ -25,6 +25,22 @@ from oracle import oracle as O  # noqa: E402
 YSEL = [0, 3, 5]  # y rows kept of the 3-D cases (all x, all z)
 
 
+G4_Z = [0, 1, 2, 25, 48, 49, 50]
+G4_X = [0, 17, 49]
+# (stage name in the reference dump, oracle call, which population array holds the result)
+G4_STAGES = [("step1", "stream_collide_save", 1), ("collide", "collide_save", 2), ("boundary", "boundary", 2), ("stream", "stream", 1),
+             ("bc_charge", "bc_charge", 1)]
+
+
+def oracle_pops(o, which):
+    """[4][27][NZ][3][NX] like ref_driver's dump_pops: X0 as d = 0, then X1 (which=1) or X2 (which=2)."""
+    out = np.empty((4, 27) + (o.shape[0], len(YSEL), o.shape[2]))
+    for l, name in enumerate(O.LATTICES):
+        out[l, 0] = o.population(name, 0)[:, YSEL, :]
+        out[l, 1:] = o.population(name, which)[:, :, YSEL, :]
+    return out
+
+
 def ref_params():
     p = O.default_params(50, 8, 51)
     p.Lx, p.Ly, p.Lz = 0.5e-6, 0.08e-6, 0.5e-6  # literals of LBM.h:40-42
@@ -118,6 +134,29 @@ def main(src, dst):
             out[f"step{m}_{k}"] = g2[f"step{m}_{k}"][:, YSEL, :].copy()
     np.savez_compressed(os.path.join(dst, "ref_g2.npz"), **out)
 
+    # ---- G4: per-kernel vectors (populations after each launch of stream_collide_save) ------
+    if os.path.exists(os.path.join(src, "ref_g4_full.npz")):
+        g4 = np.load(os.path.join(src, "ref_g4_full.npz"))
+        o = O.Oracle(p)
+        o.set_fields({k: g2["input_" + k] for k in O.FIELDS})
+        o.fast_poisson(0.0)
+        d = g4["fields0_phi"][1:-1] - o.field("phi")[1:-1]
+        shift4 = float(d.mean())
+        print("G4: shift of the first solve", shift4, "non-constancy", np.abs(d - shift4).max())
+        o.fast_poisson(shift4)
+        o.init_equilibrium()
+        out = {"shift": np.array(shift4), "ysel": np.array(YSEL), "zsel": np.array(G4_Z), "xsel": np.array(G4_X)}
+        for stage, call, which in G4_STAGES:
+            getattr(o, call)()
+            got = oracle_pops(o, which)
+            ref = g4[stage]
+            err = np.abs(got - ref).max(axis=(1, 2, 3, 4)) / np.abs(ref).max(axis=(1, 2, 3, 4))
+            print(f"G4 {stage:10s} max|oracle - reference| / max|reference| per lattice:", " ".join(f"{e:.1e}" for e in err))
+            out[stage + "_sum"] = ref.sum(axis=(2, 3, 4))
+            out[stage + "_sumsq"] = (ref * ref).sum(axis=(2, 3, 4))
+            out[stage + "_sample"] = ref[:, :, G4_Z][:, :, :, :, G4_X].copy()
+        np.savez_compressed(os.path.join(dst, "ref_g4.npz"), **out)
+
     # ---- G3 (rho, u do not depend on phi: no shift needed) ---------------------------------
     out = {"marks": g3["marks"]}
     for m in g3["marks"]:
@@ -141,7 +180,7 @@ def main(src, dst):
         import shutil
 
         shutil.copy(os.path.join(src, "ref_g6.npz"), os.path.join(dst, "ref_g6.npz"))
-    for f in ("ref_g1.npz", "ref_g2.npz", "ref_g3.npz", "ref_g5.npz"):
+    for f in ("ref_g1.npz", "ref_g2.npz", "ref_g3.npz", "ref_g4.npz", "ref_g5.npz"):
         print(f, os.path.getsize(os.path.join(dst, f)), "bytes")
 
 

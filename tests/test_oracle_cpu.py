@@ -288,3 +288,33 @@ def test_golden_current_of_the_reference_runs(O):
         o.set_fields({"c": bc("c"), "cn": bc("cn"), "Ez": bc("Ez")})
         want = float(g1["current"][i])
         assert abs(o.current() - want) <= 1e-13 * abs(want), (m, o.current(), want)
+
+
+def test_golden_G4_per_kernel_vectors(O):
+    """the four launches of stream_collide_save (LBM.cu:474-477) one by one on
+    the G2 input; after each, the oracle's populations must be the reference's (direction sums,
+    sums of squares and point samples of all four lattices on the y rows {0,3,5})."""
+    import importlib.util
+
+    g = _need("ref_g4.npz")
+    g2 = _need("ref_g2.npz")
+    spec = importlib.util.spec_from_file_location("pack_golden", os.path.join(os.path.dirname(golden_path("x")), "pack_golden.py"))
+    pk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pk)
+    p = _ref_grid(O)
+    o = O.Oracle(p)
+    o.gpu_initialization()
+    o.set_fields({k: g2["input_" + k] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+    o.fast_poisson(float(g["shift"]))
+    o.init_equilibrium()
+    zs, xs = list(g["zsel"]), list(g["xsel"])
+    for stage, call, which in pk.G4_STAGES:
+        getattr(o, call)()
+        got = pk.oracle_pops(o, which)
+        s1, s2 = got.sum(axis=(2, 3, 4)), (got * got).sum(axis=(2, 3, 4))
+        assert np.abs(s1 - g[stage + "_sum"]).max() <= 1e-12 * np.abs(g[stage + "_sum"]).max(), stage
+        assert np.abs(s2 - g[stage + "_sumsq"]).max() <= 1e-12 * np.abs(g[stage + "_sumsq"]).max(), stage
+        sample = got[:, :, zs][:, :, :, :, xs]
+        ref = g[stage + "_sample"]
+        scale = np.abs(ref).max(axis=(1, 2, 3, 4), keepdims=True)
+        assert (np.abs(sample - ref) / scale).max() <= 1e-13, stage

@@ -89,6 +89,41 @@ __global__ void klbm_chunk(const double* __restrict__ a, double* __restrict__ b,
   }
 }
 
+// as klbm_chunk, but every thread moves RPT consecutive y rows (more bytes per stream per visit)
+template <int RPT>
+__global__ void klbm_rpt(const double* __restrict__ a, double* __restrict__ b, int nx, int ny, int nz, long long dstride, long long lstride,
+                         int nxb, int rchunk) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int r = slot / nxb, xb = slot - r * nxb;
+  const int row0 = (((r / rchunk) * 8 + xcd) * rchunk + r % rchunk) * RPT;
+  if (row0 >= ny * nz) return;
+  const int lat = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = xb * 64 + lane;
+  const double* aa = a + lat * lstride;
+  double* bb = b + lat * lstride;
+  const int xm = x == 0 ? nx - 1 : x - 1, xp = x + 1 == nx ? 0 : x + 1;
+  double acc[RPT][27];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int row = row0 + q, y = row % ny, z = row / ny + 1;
+    const int ym = y == 0 ? ny - 1 : y - 1, yp = y + 1 == ny ? 0 : y + 1;
+#pragma unroll
+    for (int d = 0; d < 27; ++d) {
+      const int cx = (d % 3) - 1, cy = ((d / 3) % 3) - 1, cz = (d / 9) - 1;
+      const int xs = cx < 0 ? xp : cx > 0 ? xm : x, ys = cy < 0 ? yp : cy > 0 ? ym : y;
+      acc[q][d] = aa[(long long)d * dstride + ((long long)(z - cz) * ny + ys) * nx + xs];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int row = row0 + q, y = row % ny, z = row / ny + 1;
+    const long long o = ((long long)z * ny + y) * nx + x;
+#pragma unroll
+    for (int d = 0; d < 27; ++d) bb[(long long)d * dstride + o] = acc[q][d];
+  }
+}
+
 // lattice-interleaved layout [d][z][y][x][4]: one 32-byte element holds the four lattices'
 // population of direction d at a node; wave w of the block owns a quarter of the directions.
 struct __attribute__((aligned(32))) quad { double v[4]; };
@@ -205,7 +240,13 @@ int main() {
     CK(hipMemset(a, 0, ls * 4 * 8)); CK(hipMemset(b, 0, ls * 4 * 8));
     const double lb4 = 16.0 * 27 * 4 * nx * ny * (double)nzc;
     const int nxb = nx / 64;
-    for (int rc : {1, 8, 64}) for (int nt : {0, 1}) {
+    {
+      const long long nrows2 = (long long)ny * nzc / 2, per2 = (nrows2 + 8LL * 32 - 1) / (8LL * 32) * 32;
+      timeit("lbm-shape 4 lattices x 27, 2 rows per thread", lb4, [&] { hipLaunchKernelGGL(klbm_rpt<2>, dim3((unsigned)(8 * per2 * nxb)), dim3(256), 0, 0, a, b, nx, ny, nzc, ds, ls, nxb, 32); });
+      const long long nrows4 = (long long)ny * nzc / 4, per4 = (nrows4 + 8LL * 16 - 1) / (8LL * 16) * 16;
+      timeit("lbm-shape 4 lattices x 27, 4 rows per thread", lb4, [&] { hipLaunchKernelGGL(klbm_rpt<4>, dim3((unsigned)(8 * per4 * nxb)), dim3(256), 0, 0, a, b, nx, ny, nzc, ds, ls, nxb, 16); });
+    }
+    for (int rc : {1, 64}) for (int nt : {0}) {
       const long long nrows = (long long)ny * nzc;
       const long long per = (nrows + 8LL * rc - 1) / (8LL * rc) * rc;
       char nm[80];
@@ -218,7 +259,7 @@ int main() {
     const long long ds = (long long)nx * ny * (nzc + 2);
     const double lb4 = 16.0 * 27 * 4 * nx * ny * (double)nzc;
     const int nxb = nx / 64;
-    for (int rc : {1, 8, 64}) for (int nt : {0, 1}) {
+    for (int rc : {8}) for (int nt : {0}) {
       const long long nrows = (long long)ny * nzc;
       const long long per = (nrows + 8LL * rc - 1) / (8LL * rc) * rc;
       char nm[80];

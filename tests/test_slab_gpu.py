@@ -78,10 +78,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_processes_one_gpu_gloo(pkg, O, tmp_path):
-    """The real multi-process path (DistributedSlab + RingTransport), two ranks sharing the one
+@pytest.mark.parametrize("shape,nprocs", [((16, 12, 16), 2), ((48, 20, 48), 4)])
+def test_processes_sharing_one_gpu_gloo(pkg, O, tmp_path, shape, nprocs):
+    """The real multi-process path (DistributedSlab + RingTransport): 2 and 4 ranks sharing the one
     GPU of the box, launched like the driver launches bench.py."""
-    shape = (16, 12, 16)
     p = pkg.default_params(*shape)
     p.pb_iterations = 12
     po = O.default_params(*shape)
@@ -89,11 +89,11 @@ def test_two_processes_one_gpu_gloo(pkg, O, tmp_path):
     np.savez(tmp_path / "start.npz", **st)
     env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_GRID="x".join(map(str, shape)), OMP_NUM_THREADS="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nprocs}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_slab_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
-    parts = sorted((np.load(tmp_path / f"rank{k}.npz") for k in range(2)), key=lambda d: int(d["z0"]))
+    parts = sorted((np.load(tmp_path / f"rank{k}.npz") for k in range(nprocs)), key=lambda d: int(d["z0"]))
     got = {k: np.concatenate([d[k] for d in parts], axis=0) for k in O.FIELDS}
     err = O.rel_l2(got, want)
     assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err

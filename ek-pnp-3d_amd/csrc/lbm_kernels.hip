@@ -288,7 +288,10 @@ __device__ __forceinline__ void wall_scalar_pops(const KArgs& a, int lat, const 
 }
 
 template <int NL, bool PULL>
-__global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int top) {
+__global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int first_wall) {
+  // one launch covers the walls this context owns: blockIdx.z = 0 is wall `first_wall`
+  // (0 lower plate, 1 upper plate), blockIdx.z = 1 the upper plate
+  const int top = first_wall + (int)blockIdx.z;
   const int x = blockIdx.x * 64 + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= a.nx) return;
@@ -562,24 +565,23 @@ void launch_collide_bulk(Ctx& c, int zl_begin, int zl_end) {
 }
 
 template <int NL>
-static void wall_dispatch(Ctx& c, const KArgs& a, int top, hipStream_t stream) {
-  dim3 g((unsigned)((c.p.nx + 63) / 64), (unsigned)c.p.ny), b(64);
+static void wall_dispatch(Ctx& c, const KArgs& a, int first_wall, int nwalls, hipStream_t stream) {
+  dim3 g((unsigned)((c.p.nx + 63) / 64), (unsigned)c.p.ny, (unsigned)nwalls), b(64);
   if (c.streamed_state)
-    hipLaunchKernelGGL((k_collide_wall<NL, false>), g, b, 0, stream, a, top);
+    hipLaunchKernelGGL((k_collide_wall<NL, false>), g, b, 0, stream, a, first_wall);
   else
-    hipLaunchKernelGGL((k_collide_wall<NL, true>), g, b, 0, stream, a, top);
+    hipLaunchKernelGGL((k_collide_wall<NL, true>), g, b, 0, stream, a, first_wall);
 }
 
 void launch_collide_walls(Ctx& c, hipStream_t stream) {
   KArgs a = c.kargs();
-  for (int top = 0; top < 2; ++top) {
-    const bool owns = top ? (c.z0 + c.nzl == c.p.nz) : (c.z0 == 0);
-    if (!owns) continue;
-    switch (c.p.n_lattices) {
-      case 1: wall_dispatch<1>(c, a, top, stream); break;
-      case 3: wall_dispatch<3>(c, a, top, stream); break;
-      default: wall_dispatch<4>(c, a, top, stream); break;
-    }
+  const bool lower = c.z0 == 0, upper = c.z0 + c.nzl == c.p.nz;
+  if (!lower && !upper) return;
+  const int first_wall = lower ? 0 : 1, nwalls = (lower && upper) ? 2 : 1;
+  switch (c.p.n_lattices) {
+    case 1: wall_dispatch<1>(c, a, first_wall, nwalls, stream); break;
+    case 3: wall_dispatch<3>(c, a, first_wall, nwalls, stream); break;
+    default: wall_dispatch<4>(c, a, first_wall, nwalls, stream); break;
   }
 }
 

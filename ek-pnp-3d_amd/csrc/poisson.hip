@@ -65,7 +65,7 @@ __global__ void k_tridiag(PArgs a) {
   const double* cp = a.cprime + m;
   double dr = 0.0, di = 0.0;
   const int n = a.nz;
-#pragma unroll 4
+#pragma unroll 8
   for (int z = 1; z <= n - 2; ++z) {
     const double2 r = s[(long long)z * ms];
     const double c = cp[(long long)z * ms];
@@ -75,7 +75,7 @@ __global__ void k_tridiag(PArgs a) {
   }
   // phi[n-2] = d'[n-2]; phi[z] = d'[z] - c'[z] phi[z+1]
   double pr = dr, pi = di;
-#pragma unroll 4
+#pragma unroll 8
   for (int z = n - 3; z >= 1; --z) {
     const double2 d = s[(long long)z * ms];
     const double c = cp[(long long)z * ms];
@@ -97,10 +97,10 @@ __device__ __forceinline__ double phi_at(const PArgs& a, int x, int y, int z /*g
   return a.work[((long long)zl * a.ny + y) * a.nx + x] * a.inv_nxny;
 }
 
-#ifndef EKPNP_PHI_ZCHUNK
-#define EKPNP_PHI_ZCHUNK 16  // tuning knob: planes marched per thread
-#endif
-constexpr int PHI_ZCHUNK = EKPNP_PHI_ZCHUNK;
+// planes marched per thread: 16 on large lattices (no measurable difference between 1 and 64
+// there, profiles/r01_sweep_phi_zchunk.log), 1 on small ones where the serial chain of a column
+// would be the whole run time of the kernel
+constexpr int PHI_ZCHUNK_LARGE = 16;
 
 // One thread marches up a column of PHI_ZCHUNK planes with phi(z-1), phi(z), phi(z+1) in
 // registers: every phi value is read once for the three z uses (the x+-1 / y+-1 neighbours come
@@ -109,6 +109,7 @@ constexpr int PHI_ZCHUNK = EKPNP_PHI_ZCHUNK;
 // XCD-aware placement as in k_collide_bulk: the (y, z-chunk) rows are dealt to the 8 XCDs in
 // runs of 64 consecutive y, so the y+-1 neighbour rows are found in the XCD's own L2 (with rows
 // dealt one by one every L2 fetched all three rows: 4.1 GB fetched for 1.07 GB of phi).
+template <int PHI_ZCHUNK>
 __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, const int nrows) {
   constexpr int RCHUNK = 64;
   const int bid = blockIdx.x;
@@ -346,9 +347,14 @@ void launch_phi_efield(Ctx& c) {
   PArgs a = c.pargs();
   const int bx = c.p.nx >= 256 ? 256 : 64;
   const int nxb = (c.p.nx + bx - 1) / bx;
-  const int nrows = c.p.ny * ((c.nzl + PHI_ZCHUNK - 1) / PHI_ZCHUNK);
+  const bool small = c.nloc < (size_t)2 * 1024 * 1024;
+  const int zchunk = small ? 1 : PHI_ZCHUNK_LARGE;
+  const int nrows = c.p.ny * ((c.nzl + zchunk - 1) / zchunk);
   const long long per_xcd = ((long long)nrows + 8 * 64 - 1) / (8 * 64) * 64;
-  hipLaunchKernelGGL(k_phi_efield, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
+  if (small)
+    hipLaunchKernelGGL(k_phi_efield<1>, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
+  else
+    hipLaunchKernelGGL(k_phi_efield<PHI_ZCHUNK_LARGE>, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
 }
 
 }  // namespace ekpnp

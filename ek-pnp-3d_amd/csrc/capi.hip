@@ -80,14 +80,14 @@ extern "C" int ekpnp_default_params(ekpnp_params* p, int nx, int ny, int nz) {
 KArgs Ctx::kargs() const {
   KArgs a{};
   for (int l = 0; l < MAXL; ++l) {
-    a.A[l] = pop[cur][l];
-    a.B[l] = pop[cur ^ 1][l];
+    a.A[l] = cur_base(l);
+    a.B[l] = next_base(l);
   }
   for (int i = 0; i < EKPNP_NFIELDS; ++i) a.fld[i] = fld[i];
   a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
   a.nzl = nzl; a.z0 = z0;
   a.plane = (long long)plane;
-  a.dstride = (long long)(nzl + 2) * (long long)plane;
+  a.dstride = dstride();
   const double cs2 = p.cs_square, dt = p.dt;
   // relaxation rates, LBM.cu:488-495 (same expression order)
   const double omega_plus = 1.0 / (p.nu / cs2 / dt + 1.0 / 2.0) / dt;
@@ -153,6 +153,8 @@ static int validate(const ekpnp_params* p, int rank, int nranks, std::string& er
     err = "dx, dy, dz, dt, CFL, cs_square, Lx, Ly, Lz must be positive"; return EKPNP_ERR_INVALID;
   }
   if (p->pb_iterations < 0) { err = "pb_iterations must be >= 0"; return EKPNP_ERR_INVALID; }
+  if (p->in_place != 0 && p->in_place != 1) { err = "in_place must be 0 or 1"; return EKPNP_ERR_INVALID; }
+  if (p->in_place && nranks > 1) { err = "in_place is implemented for single-slab contexts"; return EKPNP_ERR_INVALID; }
   return EKPNP_OK;
 }
 
@@ -184,8 +186,15 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
     return bail(EKPNP_ERR_HIP);
   }
   c.own_stream = true;
-  const size_t popbytes = (size_t)Q * (c.nzl + 2) * c.plane * sizeof(double);
-  for (int b = 0; b < 2; ++b)
+  // In-place mode: one buffer per lattice with `shift` spare planes.  A sweep writes plane z of
+  // the new state `shift` planes below (parity 0, bulk launches of `zchunk` planes in ascending z)
+  // or above (parity 1, descending) where plane z of the old state lies; shift >= zchunk + 1
+  // guarantees that a launch only overwrites planes every later launch is done with.
+  c.inplace = p->in_place != 0;
+  c.zchunk = c.inplace ? 64 : 0;
+  c.shift = c.inplace ? c.zchunk + 1 : 0;
+  const size_t popbytes = (size_t)Q * (c.nzl + 2 + c.shift) * c.plane * sizeof(double);
+  for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
     for (int l = 0; l < p->n_lattices; ++l)
       if ((rc = dev_alloc(c, (void**)&c.pop[b][l], popbytes))) return bail(rc);
   for (int i = 0; i < EKPNP_NFIELDS; ++i) {
@@ -534,9 +543,29 @@ extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
   if (c.nranks != 1) return fail(c, "slab context: use ekpnp_collide_boundary_planes/interior_planes + halo transport");
   // (running the two wall planes on a second stream beside the bulk kernel was measured: no gain,
   // the bulk kernel already saturates HBM and merely stretches - profiles/r01_bench_after_tuning.log)
-  int rc = collide_range(c, bulk_begin(c), bulk_end(c), true);
-  if (rc) return rc;
-  launch_collide_walls(c, c.stream);
+  const int zb = bulk_begin(c), ze = bulk_end(c);
+  if (!c.inplace) {
+    int rc = collide_range(c, zb, ze, true);
+    if (rc) return rc;
+    launch_collide_walls(c, c.stream, true, true);
+  } else {
+    // ordered sweep: the wall plane on the side the lattice moves towards first, bulk launches of
+    // zchunk planes towards the other side, the far wall plane last
+    hipEvent_t* stop = nullptr;
+    const bool up = c.cur == 0;  // ascending z, new state written `shift` planes below
+    launch_collide_walls(c, c.stream, up, !up);
+    int rc = timing_begin(c, &stop);
+    if (rc) return rc;
+    if (up)
+      for (int z = zb; z < ze; z += c.zchunk) launch_collide_bulk(c, z, z + c.zchunk < ze ? z + c.zchunk : ze);
+    else
+      for (int z = ze; z > zb; z -= c.zchunk) launch_collide_bulk(c, z - c.zchunk > zb ? z - c.zchunk : zb, z);
+    if (stop) {
+      HIPCHK(c, hipEventRecord(*stop, c.stream));
+      c.timed_nodes = (long long)(ze - zb) * (long long)c.plane;
+    }
+    launch_collide_walls(c, c.stream, !up, up);
+  }
   finish_collide(c);
   launch_ghost_wrap(c);  // z-periodic ghost loop of gpu_stream, LBM.cu:1972,1975
   HIPCHK(c, hipGetLastError());
@@ -689,7 +718,7 @@ extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_stream_collide_save");
   if (c.collide_phase != 0) return fail(c, "ekpnp_collide_boundary_planes called twice");
-  launch_collide_walls(c, c.stream);
+  launch_collide_walls(c, c.stream, true, true);
   if (c.z0 != 0) launch_collide_bulk(c, 0, 1);
   if (c.z0 + c.nzl != c.p.nz) launch_collide_bulk(c, c.nzl - 1, c.nzl);
   c.collide_phase = 1;

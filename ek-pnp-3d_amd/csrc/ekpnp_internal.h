@@ -88,7 +88,7 @@ void launch_pbe(Ctx&);
 void launch_pbe_relax(Ctx&, double* phi_old, double omega);
 void launch_init_equilibrium(Ctx&);
 void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
-void launch_collide_walls(Ctx&, hipStream_t stream);
+void launch_collide_walls(Ctx&, hipStream_t stream, bool lower, bool upper);
 void launch_ghost_wrap(Ctx&);
 void launch_halo_pack(Ctx&, int buffer);
 void launch_halo_unpack(Ctx&);
@@ -113,8 +113,24 @@ struct Ctx {
   size_t plane = 0, nloc = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  double* pop[2][MAXL] = {};   // [buffer][lattice]
-  int cur = 0;                 // buffer holding the current state
+  double* pop[2][MAXL] = {};   // [buffer][lattice]; in-place mode uses pop[0] only
+  int cur = 0;                 // A/B mode: buffer holding the current state.  In-place mode: the
+                               // parity of the storage offset (0: lattice at +shift planes, the
+                               // next sweep runs z-ascending and writes at offset 0; 1: mirror)
+  bool inplace = false;
+  int shift = 0;               // planes the lattice moves per sweep in in-place mode (0 in A/B mode)
+  int zchunk = 0;              // planes per bulk launch in in-place mode (shift >= zchunk + 1)
+  // base pointer of lattice l's CURRENT state (plane zg = 0 is the ghost plane below) and the
+  // direction stride shared by all population addressing
+  double* cur_base(int l) const {
+    if (!inplace) return pop[cur][l];
+    return pop[0][l] ? pop[0][l] + (size_t)(cur == 0 ? shift : 0) * plane : nullptr;
+  }
+  double* next_base(int l) const {
+    if (!inplace) return pop[cur ^ 1][l];
+    return pop[0][l] ? pop[0][l] + (size_t)(cur == 0 ? 0 : shift) * plane : nullptr;
+  }
+  long long dstride() const { return (long long)(nzl + 2 + shift) * (long long)plane; }
   bool rhs_ready = false;      // work[] holds the Poisson rhs of the current c, cn (written by the collide)
   bool streamed_state = true;  // true: pop[cur] holds X1 (post-stream, e.g. fresh equilibrium);
                                // false: pop[cur] holds post-collision populations (pull next)

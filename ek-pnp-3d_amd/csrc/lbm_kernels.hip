@@ -530,7 +530,7 @@ void launch_pbe_relax(Ctx& c, double* phi_old, double omega) {
 void launch_init_equilibrium(Ctx& c) {
   KArgs a = c.kargs();
   // write into the CURRENT buffer: kargs() exposes it as A (const); B is the other one
-  for (int l = 0; l < MAXL; ++l) a.B[l] = c.pop[c.cur][l];
+  for (int l = 0; l < MAXL; ++l) a.B[l] = c.cur_base(l);
   dim3 g = grid1d((long long)c.nloc, 128), b(128);
   switch (c.p.n_lattices) {
     case 1: hipLaunchKernelGGL(k_init_equilibrium<1>, g, b, 0, c.stream, a); break;
@@ -573,9 +573,9 @@ static void wall_dispatch(Ctx& c, const KArgs& a, int first_wall, int nwalls, hi
     hipLaunchKernelGGL((k_collide_wall<NL, true>), g, b, 0, stream, a, first_wall);
 }
 
-void launch_collide_walls(Ctx& c, hipStream_t stream) {
+void launch_collide_walls(Ctx& c, hipStream_t stream, bool want_lower, bool want_upper) {
   KArgs a = c.kargs();
-  const bool lower = c.z0 == 0, upper = c.z0 + c.nzl == c.p.nz;
+  const bool lower = want_lower && c.z0 == 0, upper = want_upper && c.z0 + c.nzl == c.p.nz;
   if (!lower && !upper) return;
   const int first_wall = lower ? 0 : 1, nwalls = (lower && upper) ? 2 : 1;
   switch (c.p.n_lattices) {
@@ -586,10 +586,9 @@ void launch_collide_walls(Ctx& c, hipStream_t stream) {
 }
 
 void launch_ghost_wrap(Ctx& c) {
-  double** p = c.pop[c.cur];
+  double* p[MAXL] = {c.cur_base(0), c.cur_base(1), c.cur_base(2), c.cur_base(3)};
   dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
-  hipLaunchKernelGGL(k_ghost_wrap, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane,
-                     (long long)(c.nzl + 2) * (long long)c.plane, c.nzl);
+  hipLaunchKernelGGL(k_ghost_wrap, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane, c.dstride(), c.nzl);
 }
 
 void launch_halo_pack(Ctx& c, int buffer) {

@@ -35,7 +35,7 @@ class EkpnpError(RuntimeError):
 class Params(C.Structure):
     """Mirror of `ekpnp_params` (include/ekpnp.h)."""
 
-    _fields_ = [(n, C.c_int32) for n in ("nx", "ny", "nz", "n_lattices", "pb_iterations", "reserved0")] + [
+    _fields_ = [(n, C.c_int32) for n in ("nx", "ny", "nz", "n_lattices", "pb_iterations", "in_place")] + [
         (n, C.c_double)
         for n in (
             "Lx Ly Lz dx dy dz CFL dt cs_square rho0 chargeinf voltage voltage2 Ext eps "

@@ -60,7 +60,10 @@ typedef struct ekpnp_params {
                             /* and Ra == 0)                                     */
   int32_t pb_iterations;    /* Poisson-Boltzmann sweeps in initialization();    */
                             /* the reference loops i = 0..500 -> 501            */
-  int32_t reserved0;
+  int32_t in_place;         /* 0: two population buffers (A/B, fastest). 1: ONE buffer,   */
+                            /* each sweep writes the lattice shifted by 65 planes in z and  */
+                            /* the shift direction alternates: 424N -> ~240N bytes of       */
+                            /* populations, same results (single-slab contexts only)        */
   double Lx, Ly, Lz;        /* LBM.h:40-42; Lx=nx*dx, Ly=ny*dy, Lz=(nz-1)*dz    */
   double dx, dy, dz;        /* LBM.h:43-45                                      */
   double CFL;               /* LBM.h:51                                         */

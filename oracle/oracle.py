@@ -25,7 +25,7 @@ class Params(C.Structure):
     """Mirror of `ekpnp_params` (include/ekpnp.h)."""
 
     _fields_ = (
-        [(n, C.c_int32) for n in ("nx", "ny", "nz", "n_lattices", "pb_iterations", "reserved0")]
+        [(n, C.c_int32) for n in ("nx", "ny", "nz", "n_lattices", "pb_iterations", "in_place")]
         + [
             (n, C.c_double)
             for n in (

@@ -407,3 +407,40 @@ def test_graph_replay_is_bitwise_the_eager_path(pkg, O, monkeypatch):
     for k in outs[0][0]:
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
     assert abs(outs[0][1] - 26 * p.dt) < 1e-22
+
+
+@pytest.mark.parametrize("shape", [(24, 6, 150), (16, 12, 17), (70, 3, 66)])
+def test_in_place_mode_is_bitwise_the_two_buffer_mode(pkg, O, shape):
+    """in_place = 1: one population buffer, every sweep writes the lattice 65 planes further down /
+    up (bulk launches of 64 planes in z order).  Same kernels, same arithmetic per node: the
+    results must be identical bit for bit, with about half the population memory."""
+    po = O.default_params(*shape)
+    po.pb_iterations = 12
+    outs, mem = [], []
+    for mode in (0, 1):
+        p = _mirror(pkg, po)
+        p.in_place = mode
+        with pkg.Solver(p) as s:
+            s.initialization()
+            s.set_fields(O.perturb_fields(po, s.fields()))
+            s.fast_Poisson(); s.init_equilibrium()
+            s.step(7)
+            s.stream_collide_save(); s.fast_Poisson()
+            s.init_equilibrium()  # restart from the fields in the other parity
+            s.step(4)
+            outs.append(s.fields())
+            mem.append(s.device_bytes())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert mem[1] < mem[0]
+
+
+def test_in_place_mode_vs_oracle_and_rejected_on_slabs(pkg, O):
+    po = O.default_params(20, 8, 140)
+    po.pb_iterations = 10
+    po.in_place = 1
+    res = _run_pair(pkg, O, po, [1, 2, 9])
+    _assert_all(res)
+    p = _mirror(pkg, po)
+    with pytest.raises(pkg.EkpnpError):
+        pkg.Solver(p, rank=0, nranks=2)

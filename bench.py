@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--ic", default="perturbed", choices=["perturbed", "uniform"])
     ap.add_argument("--pb-iterations", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-place", action="store_true", help="one population buffer (ekpnp_params.in_place): half the memory, N=1 only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="transport of the N>1 path; gloo (host-staged) only to rehearse the multi-rank flow")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: put every rank on device 0")
@@ -185,6 +186,8 @@ def main():
         p.chargeinf, p.TH, p.exf = 0.0, 0.0, 1e9
     if args.pb_iterations is not None:
         p.pb_iterations = args.pb_iterations
+    if args.in_place:
+        p.in_place = 1
 
     if world == 1:
         sol = pkg.Solver(p)
@@ -275,6 +278,7 @@ def main():
                 + (f", z-slabs of {nz} planes over {world} GPUs" if world > 1 else ""),
                 "grid": [nx, ny, nz_global],
                 "lattices": nl,
+                "in_place": bool(args.in_place),
                 "ic": ic_note + (" + closed-form 3-D perturbation" if args.ic == "perturbed" else ""),
                 "b_alg_step_bytes_per_node": b_alg_step(nl),
                 "step_roofline_frac": round(b_alg_step(nl) * mlups / world * 1e6 / (HBM_PEAK_GBS * 1e9), 4),

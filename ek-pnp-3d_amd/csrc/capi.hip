@@ -191,7 +191,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   // or above (parity 1, descending) where plane z of the old state lies; shift >= zchunk + 1
   // guarantees that a launch only overwrites planes every later launch is done with.
   c.inplace = p->in_place != 0;
-  c.zchunk = c.inplace ? 64 : 0;
+  c.zchunk = c.inplace ? (c.nzl / 4 < 1 ? 1 : c.nzl / 4 > 64 ? 64 : c.nzl / 4) : 0;
   c.shift = c.inplace ? c.zchunk + 1 : 0;
   const size_t popbytes = (size_t)Q * (c.nzl + 2 + c.shift) * c.plane * sizeof(double);
   for (int b = 0; b < (c.inplace ? 1 : 2); ++b)

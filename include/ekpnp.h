@@ -61,9 +61,10 @@ typedef struct ekpnp_params {
   int32_t pb_iterations;    /* Poisson-Boltzmann sweeps in initialization();    */
                             /* the reference loops i = 0..500 -> 501            */
   int32_t in_place;         /* 0: two population buffers (A/B, fastest). 1: ONE buffer,   */
-                            /* each sweep writes the lattice shifted by 65 planes in z and  */
-                            /* the shift direction alternates: 424N -> ~240N bytes of       */
-                            /* populations, same results (single-slab contexts only)        */
+                            /* each sweep writes the lattice shifted by min(nz/4,64)+1      */
+                            /* planes in z and the shift direction alternates: 2 x 216 N    */
+                            /* -> ~1.13 x 216 N bytes of populations per lattice at nz=512, */
+                            /* same results bit for bit (single-slab contexts only)         */
   double Lx, Ly, Lz;        /* LBM.h:40-42; Lx=nx*dx, Ly=ny*dy, Lz=(nz-1)*dz    */
   double dx, dy, dz;        /* LBM.h:43-45                                      */
   double CFL;               /* LBM.h:51                                         */

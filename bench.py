@@ -45,18 +45,26 @@ def b_alg_step(nl: int) -> int:
     return b_alg_lbm(nl) + (48 if nl > 1 else 0)
 
 
-def parse_workload(name: str, free_bytes: int):
+def parse_workload(name: str, free_bytes: int, in_place: bool = False):
+    """-> (name, grid, lattices, in_place).  auto: cfg3 with two population buffers if 248 GB are
+    free, else cfg3 in place (146 GB), else cfg2."""
     if name == "auto":
-        need3 = 2 * 4 * 27 * 514 * 512 * 512 * 8 + 16 * 512**3 * 8
-        name = "cfg3" if free_bytes > need3 * 1.02 else "cfg2"
+        fields = 16 * 512**3 * 8
+        need3 = 2 * 4 * 27 * 514 * 512 * 512 * 8 + fields
+        need3_ip = 4 * 27 * (514 + 65) * 512 * 512 * 8 + fields
+        if in_place or free_bytes <= need3 * 1.02:
+            in_place = True
+        name = "cfg3" if free_bytes > (need3_ip if in_place else need3) * 1.02 else "cfg2"
+        if name == "cfg2":
+            in_place = False
     if name == "cfg3":
-        return name, (512, 512, 512), 4
+        return name, (512, 512, 512), 4, in_place
     if name == "cfg2":
-        return name, (256, 256, 256), 3
+        return name, (256, 256, 256), 3, in_place
     if name == "cfg1":
-        return name, (64, 64, 64), 1
+        return name, (64, 64, 64), 1, in_place
     nx, ny, nz = (int(v) for v in name.lower().split("x"))
-    return name, (nx, ny, nz), 4
+    return name, (nx, ny, nz), 4, in_place
 
 
 def gouy_chapman_state(sol, p):
@@ -165,7 +173,7 @@ def main():
     pkg = G.load_package()
 
     free_b, total_b = torch.cuda.mem_get_info()
-    wname, (nx, ny, nz), nl = parse_workload(args.workload, free_b)
+    wname, (nx, ny, nz), nl, use_in_place = parse_workload(args.workload, free_b, args.in_place and world == 1)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: WPS440
@@ -186,7 +194,7 @@ def main():
         p.chargeinf, p.TH, p.exf = 0.0, 0.0, 1e9
     if args.pb_iterations is not None:
         p.pb_iterations = args.pb_iterations
-    if args.in_place:
+    if use_in_place and world == 1:
         p.in_place = 1
 
     if world == 1:
@@ -278,7 +286,7 @@ def main():
                 + (f", z-slabs of {nz} planes over {world} GPUs" if world > 1 else ""),
                 "grid": [nx, ny, nz_global],
                 "lattices": nl,
-                "in_place": bool(args.in_place),
+                "in_place": bool(p.in_place),
                 "ic": ic_note + (" + closed-form 3-D perturbation" if args.ic == "perturbed" else ""),
                 "b_alg_step_bytes_per_node": b_alg_step(nl),
                 "step_roofline_frac": round(b_alg_step(nl) * mlups / world * 1e6 / (HBM_PEAK_GBS * 1e9), 4),

@@ -13,6 +13,7 @@ from .solver import (  # noqa: F401
     EkpnpError,
     Params,
     Solver,
+    compute_parameters,
     default_params,
     exported_symbols,
     library_path,

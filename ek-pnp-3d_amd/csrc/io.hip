@@ -8,6 +8,7 @@
 // The writers keep the reference's text formats byte for byte (Tecplot POINT zones, the lossy
 // "%10.6f" restart file) and its wall extrapolation of rho, c, cn, u (LBM.cu:2527-2542); a FILE*
 // cannot cross a C ABI, so they take a path and an append flag.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -161,4 +162,33 @@ extern "C" int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time) {
   c.t = *time;
   c.rhs_ready = false;
   return EKPNP_OK;
+}
+
+extern "C" int ekpnp_compute_parameters(const ekpnp_params* p, double* T, double* M, double* C, double* Fe, double* Pr) {
+  if (!p) return EKPNP_ERR_INVALID;
+  // LBM.cu:2440-2444, same expressions (charge0_host there is chargeinf, LBM.cu:2436)
+  if (M) *M = std::sqrt(p->eps / p->rho0) / p->K;
+  if (T) *T = p->eps * p->voltage / p->K / p->nu / p->rho0;
+  if (C) *C = p->chargeinf * p->Lz * p->Lz / (p->voltage * p->eps);
+  if (Fe) *Fe = p->K * p->voltage / p->diffu;
+  if (Pr) *Pr = p->nu / p->D;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_save_scalar(ekpnp_ctx* ctx, const char* name, int field_id, unsigned n, unsigned nsteps) {
+  NEEDCTX(ctx);
+  if (!name || field_id < 0 || field_id >= EKPNP_NFIELDS) return fail(c, "bad name or field id");
+  if (std::strlen(name) > 100) return fail(c, "file name too long");  // the reference assumes it fits 128 chars
+  const int ndigits = (int)std::floor(std::log10((double)(nsteps ? nsteps : 1)) + 1.0);  // LBM.cu:2461
+  char format[16], filename[160];
+  std::snprintf(format, sizeof format, "%%s%%0%dd.bin", ndigits);                        // LBM.cu:2465
+  std::snprintf(filename, sizeof filename, format, name, n);
+  std::vector<double> h(c.nloc);
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  HIPCHK(c, hipMemcpy(h.data(), c.fld[field_id], c.nloc * sizeof(double), hipMemcpyDeviceToHost));
+  FILE* f = std::fopen(filename, "wb");
+  if (!f) return fail(c, "cannot open scalar file");
+  const size_t w = std::fwrite(h.data(), 1, c.nloc * sizeof(double), f);  // LBM.cu:2475
+  std::fclose(f);
+  return w == c.nloc * sizeof(double) ? EKPNP_OK : fail(c, "short write on scalar file");
 }

@@ -134,6 +134,8 @@ def load_library():
         "ekpnp_save_data_tecplot": (i32, [ctx, C.c_char_p, i32, dbl, i32]),
         "ekpnp_save_data_end": (i32, [ctx, C.c_char_p, i32, dbl]),
         "ekpnp_read_data": (i32, [ctx, C.c_char_p, pd]),
+        "ekpnp_compute_parameters": (i32, [C.POINTER(Params), pd, pd, pd, pd, pd]),
+        "ekpnp_save_scalar": (i32, [ctx, C.c_char_p, i32, C.c_uint, C.c_uint]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it
@@ -149,6 +151,15 @@ def default_params(nx: int, ny: int, nz: int) -> Params:
     if rc:
         raise EkpnpError(f"ekpnp_default_params({nx},{ny},{nz}) -> {rc}")
     return p
+
+
+def compute_parameters(p: Params) -> dict:
+    """compute_parameters (LBM.cu:2419-2446): the dimensionless groups T, M, C, Fe, Pr."""
+    v = [C.c_double() for _ in range(5)]
+    rc = load_library().ekpnp_compute_parameters(C.byref(p), *[C.byref(x) for x in v])
+    if rc:
+        raise EkpnpError(f"ekpnp_compute_parameters -> {rc}")
+    return dict(zip(("T", "M", "C", "Fe", "Pr"), (x.value for x in v)))
 
 
 class Solver:
@@ -286,6 +297,9 @@ class Solver:
 
     def save_data_end(self, path: str, time: float, append: bool = False):
         self._ck(self._L.ekpnp_save_data_end(self._h, os.fsencode(path), int(append), float(time)))
+
+    def save_scalar(self, name: str, field: str, n: int, nsteps: int = 1000):
+        self._ck(self._L.ekpnp_save_scalar(self._h, os.fsencode(name), FIELD_ID[field], int(n), int(nsteps)))
 
     def read_data(self, path: str) -> float:
         t = C.c_double()

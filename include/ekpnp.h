@@ -179,6 +179,15 @@ int ekpnp_save_data_end(ekpnp_ctx* ctx, const char* path, int append, double tim
  * LBM.cu:2632-2671: fills the 11 fields from a save_data_end file (main.cu:161-164). */
 int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time);
 
+/* void compute_parameters(double* T, double* M, double* C, double* Fe, double* Pr) — LBM.h:171,
+ * LBM.cu:2419-2446: the dimensionless groups main.cu:38 computes for its banner.  Pure host
+ * arithmetic on the parameter struct (needs no context and no device). */
+int ekpnp_compute_parameters(const ekpnp_params* p, double* T, double* M, double* C, double* Fe, double* Pr);
+/* void save_scalar(const char* name, double* scalar_gpu, double* scalar_host, unsigned n) —
+ * LBM.h:168, LBM.cu:2454-2490: raw FP64 dump of one field into "<name><n zero-padded>.bin"; the
+ * pad width is floor(log10(nsteps) + 1) like the reference derives from its NSTEPS. */
+int ekpnp_save_scalar(ekpnp_ctx* ctx, const char* name, int field_id, unsigned n, unsigned nsteps);
+
 /* ---- measurement hooks (bench.py; no reference counterpart) ------------------ */
 /* When enabled, every launch of the bulk collide/stream kernel is bracketed by
  * HIP events on the context's stream; the sum is returned by ..._get. */

@@ -92,3 +92,16 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"oracle", txt, re.I), f"{f} mentions the oracle"
+
+
+def test_compute_parameters_matches_the_reference_formulas(pkg):
+    """compute_parameters, LBM.cu:2440-2444 (host arithmetic: runs without a GPU)."""
+    import math
+
+    p = pkg.default_params(50, 8, 51)
+    d = pkg.compute_parameters(p)
+    assert d["M"] == math.sqrt(p.eps / p.rho0) / p.K
+    assert d["T"] == p.eps * p.voltage / p.K / p.nu / p.rho0
+    assert d["C"] == p.chargeinf * p.Lz * p.Lz / (p.voltage * p.eps)
+    assert d["Fe"] == p.K * p.voltage / p.diffu
+    assert d["Pr"] == p.nu / p.D == 1.0

@@ -194,3 +194,15 @@ def test_cpp_driver_reproduces_the_library_calls(pkg, O, tmp_path):
     assert r2.returncode == 0 and "Reading previous data" in r2.stdout, r2.stderr
     r3 = subprocess.run([exe, "--nx", "8", "--ny", "8", "--nz", "2"], capture_output=True, text=True, timeout=60)
     assert r3.returncode != 0 and "failed" in r3.stderr  # errors are reported, never a crash
+
+
+def test_save_scalar_names_and_bytes(pkg, tmp_path):
+    """save_scalar, LBM.cu:2454-2490: "<name><n padded to the digits of NSTEPS>.bin", raw FP64."""
+    p = pkg.default_params(12, 6, 8)
+    with pkg.Solver(p) as s:
+        a = np.arange(12 * 6 * 8, dtype=np.float64).reshape(s.shape)
+        s.set_field("ux", a)
+        s.save_scalar(str(tmp_path / "ux"), "ux", 37, nsteps=1000)
+        assert np.array_equal(np.fromfile(tmp_path / "ux0037.bin"), a.ravel())
+        s.save_scalar(str(tmp_path / "ux"), "ux", 5, nsteps=99)
+        assert (tmp_path / "ux05.bin").exists()

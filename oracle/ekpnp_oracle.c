@@ -8,17 +8,24 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it;
  * the product library never links, imports or calls anything in oracle/.
  *
- * Pinning: the reference ships no tests, fixtures or golden vectors,
- * so this restatement is pinned against tests/golden/ref_*.npz, which were produced
- * by the reference's own kernels built for gfx950 (oracle/build_ref.sh) and run on an
- * MI355X (see DESIGN.md "Oracle").  Two reference ambiguities are canonicalised here
- * exactly as SURVEY.md §8(c) prescribes:
+ * Pinning: the reference ships no tests, fixtures or golden vectors, so this
+ * restatement is pinned against tests/golden/ref_g{1..6}.npz: outputs of the reference's OWN
+ * kernels, built for gfx950 by oracle/build_ref.sh (hipify-perl from the image renames the
+ * cuda* / cufft* identifiers; nothing else is edited) and run on an MI355X by
+ * tests/golden/make_golden.py.  Measured agreement (tests/test_oracle_cpu.py):
+ * initialization() with its 501 sweeps 4e-15, 100 steps of the default run <= 2e-14, 50 steps of
+ * a 3-D perturbed run <= 4e-15, 3000 steps of a body-force channel 7e-16 / 1.5e-12 (u), the
+ * populations after each single kernel of stream_collide_save 1.2e-15, velocity always <= 4e-9.
+ * Two reference ambiguities are canonicalised here exactly as SURVEY.md §8(c) prescribes:
  *   (1) the z==0 thread of gpu_collide_save reads node z=1's rest populations
  *       (LBM.cu:664-667) which the z=1 thread overwrites in place (LBM.cu:1711-1714):
  *       the oracle always reads the PRE-collision values;
  *   (2) the DC mode of the Poisson solve is divided by mu=1 in the reference
- *       (poisson.cu:177) and carries FFT-library rounding residue: dc_mode==0 forces
- *       it to exactly 0 (canonical), dc_mode==1 keeps the reference's division.
+ *       (poisson.cu:177) and carries the FFT library's rounding residue, which shifts the
+ *       interior phi of every solve by one constant (up to 4e-4 on a 5e-3 field with hipFFT):
+ *       dc_mode==0 forces the mode to exactly 0 (canonical).  To replay a particular run of the
+ *       reference the measured constant of every solve is injected (oracle_set_dc_shift,
+ *       oracle_step_shifts, oracle_initialization_shifts); the fixtures carry those constants.
  *
  * Every function cites the reference lines it follows.
  */

@@ -88,6 +88,7 @@ KArgs Ctx::kargs() const {
   a.nzl = nzl; a.z0 = z0;
   a.plane = (long long)plane;
   a.dstride = dstride();
+  a.dstrideB = a.dstride;
   const double cs2 = p.cs_square, dt = p.dt;
   // relaxation rates, LBM.cu:488-495 (same expression order)
   const double omega_plus = 1.0 / (p.nu / cs2 / dt + 1.0 / 2.0) / dt;
@@ -154,7 +155,6 @@ static int validate(const ekpnp_params* p, int rank, int nranks, std::string& er
   }
   if (p->pb_iterations < 0) { err = "pb_iterations must be >= 0"; return EKPNP_ERR_INVALID; }
   if (p->in_place != 0 && p->in_place != 1) { err = "in_place must be 0 or 1"; return EKPNP_ERR_INVALID; }
-  if (p->in_place && nranks > 1) { err = "in_place is implemented for single-slab contexts"; return EKPNP_ERR_INVALID; }
   return EKPNP_OK;
 }
 
@@ -197,6 +197,9 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
     for (int l = 0; l < p->n_lattices; ++l)
       if ((rc = dev_alloc(c, (void**)&c.pop[b][l], popbytes))) return bail(rc);
+  if (c.inplace && nranks > 1)
+    for (int l = 0; l < p->n_lattices; ++l)
+      if ((rc = dev_alloc(c, (void**)&c.stage[l], (size_t)Q * 2 * c.plane * sizeof(double)))) return bail(rc);
   for (int i = 0; i < EKPNP_NFIELDS; ++i) {
     if ((rc = dev_alloc(c, (void**)&c.fld[i], c.nloc * sizeof(double)))) return bail(rc);
     c.fld_owned[i] = true;
@@ -256,6 +259,8 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   for (int b = 0; b < 2; ++b)
     for (int l = 0; l < MAXL; ++l)
       if (c.pop[b][l]) (void)hipFree(c.pop[b][l]);
+  for (int l = 0; l < MAXL; ++l)
+    if (c.stage[l]) (void)hipFree(c.stage[l]);
   for (int i = 0; i < EKPNP_NFIELDS; ++i)
     if (c.fld[i] && c.fld_owned[i]) (void)hipFree(c.fld[i]);
   if (c.work) (void)hipFree(c.work);
@@ -531,6 +536,15 @@ static int collide_range(Ctx& c, int zb, int ze, bool timed) {
   return EKPNP_OK;
 }
 
+// bulk launches of planes [zb, ze) in the z order the in-place shift requires (one launch in A/B mode)
+static void ordered_bulk(Ctx& c, int zb, int ze) {
+  if (!c.inplace) { launch_collide_bulk(c, zb, ze); return; }
+  if (c.cur == 0)
+    for (int z = zb; z < ze; z += c.zchunk) launch_collide_bulk(c, z, z + c.zchunk < ze ? z + c.zchunk : ze);
+  else
+    for (int z = ze; z > zb; z -= c.zchunk) launch_collide_bulk(c, z - c.zchunk > zb ? z - c.zchunk : zb, z);
+}
+
 static void finish_collide(Ctx& c) {
   c.cur ^= 1;
   c.streamed_state = false;
@@ -556,10 +570,7 @@ extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
     launch_collide_walls(c, c.stream, up, !up);
     int rc = timing_begin(c, &stop);
     if (rc) return rc;
-    if (up)
-      for (int z = zb; z < ze; z += c.zchunk) launch_collide_bulk(c, z, z + c.zchunk < ze ? z + c.zchunk : ze);
-    else
-      for (int z = ze; z > zb; z -= c.zchunk) launch_collide_bulk(c, z - c.zchunk > zb ? z - c.zchunk : zb, z);
+    ordered_bulk(c, zb, ze);
     if (stop) {
       HIPCHK(c, hipEventRecord(*stop, c.stream));
       c.timed_nodes = (long long)(ze - zb) * (long long)c.plane;
@@ -699,8 +710,13 @@ extern "C" int ekpnp_phi_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, s
 extern "C" int ekpnp_halo_pack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
-  // between the boundary and the interior call the fresh planes are in the NEXT buffer
-  launch_halo_pack(c, c.collide_phase == 1 ? (c.cur ^ 1) : c.cur);
+  if (c.inplace) {
+    if (c.collide_phase != 1) return fail(c, "in-place slab: ekpnp_halo_pack belongs between the boundary and the interior call");
+    launch_halo_pack_stage(c);
+  } else {
+    // between the boundary and the interior call the fresh planes are in the NEXT buffer
+    launch_halo_pack(c, c.collide_phase == 1 ? (c.cur ^ 1) : c.cur);
+  }
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;
 }
@@ -718,9 +734,19 @@ extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_stream_collide_save");
   if (c.collide_phase != 0) return fail(c, "ekpnp_collide_boundary_planes called twice");
-  launch_collide_walls(c, c.stream, true, true);
-  if (c.z0 != 0) launch_collide_bulk(c, 0, 1);
-  if (c.z0 + c.nzl != c.p.nz) launch_collide_bulk(c, c.nzl - 1, c.nzl);
+  KArgs lo = c.kargs(), hi = lo;
+  if (c.inplace) {
+    // redirect the stores of plane zg = 1 / zg = nzl into the staging planes 0 / 1
+    lo.dstrideB = hi.dstrideB = 2 * (long long)c.plane;
+    for (int l = 0; l < c.p.n_lattices; ++l) {
+      lo.B[l] = c.stage[l] - (ptrdiff_t)c.plane;                          // (d, zg=1)   -> stage[d][0]
+      hi.B[l] = c.stage[l] + (ptrdiff_t)c.plane - (ptrdiff_t)c.nzl * (ptrdiff_t)c.plane;  // (d, zg=nzl) -> stage[d][1]
+    }
+  }
+  launch_collide_walls(c, lo, c.stream, true, false);
+  launch_collide_walls(c, hi, c.stream, false, true);
+  if (c.z0 != 0) launch_collide_bulk(c, lo, 0, 1);
+  if (c.z0 + c.nzl != c.p.nz) launch_collide_bulk(c, hi, c.nzl - 1, c.nzl);
   c.collide_phase = 1;
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;
@@ -729,9 +755,16 @@ extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
 extern "C" int ekpnp_collide_interior_planes(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (c.collide_phase != 1) return fail(c, "ekpnp_collide_interior_planes without ekpnp_collide_boundary_planes");
-  int rc = collide_range(c, 1, c.nzl - 1, true);
+  hipEvent_t* stop = nullptr;
+  int rc = timing_begin(c, &stop);
   if (rc) return rc;
+  ordered_bulk(c, 1, c.nzl - 1);
+  if (stop) {
+    HIPCHK(c, hipEventRecord(*stop, c.stream));
+    c.timed_nodes = (long long)(c.nzl - 2) * (long long)c.plane;
+  }
   finish_collide(c);
+  if (c.inplace) launch_unstage(c);  // the two staged planes take their place in the shifted lattice
   c.collide_phase = 0;
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;

@@ -53,7 +53,8 @@ struct KArgs {
   int nx, ny, nz;              // global lattice
   int nzl, z0;                 // owned planes and the global index of the first one
   long long plane;             // nx*ny
-  long long dstride;           // (nzl+2)*plane
+  long long dstride;           // direction stride of A: (nzl+2+shift)*plane
+  long long dstrideB;          // direction stride of B (differs only when B is the 2-plane staging buffer)
   // derived physics (host-side, in the reference's expression order, LBM.cu:488-495,1660-1661)
   double wp[MAXL], wm[MAXL];   // omega_plus*dt / omega_minus*dt per lattice
   double mob[MAXL];            // drift mobility: 0, K, Kn, 0
@@ -88,6 +89,10 @@ void launch_pbe(Ctx&);
 void launch_pbe_relax(Ctx&, double* phi_old, double omega);
 void launch_init_equilibrium(Ctx&);
 void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
+void launch_collide_bulk(Ctx&, const KArgs&, int zl_begin, int zl_end);
+void launch_collide_walls(Ctx&, const KArgs&, hipStream_t stream, bool lower, bool upper);
+void launch_halo_pack_stage(Ctx&);
+void launch_unstage(Ctx&);
 void launch_collide_walls(Ctx&, hipStream_t stream, bool lower, bool upper);
 void launch_ghost_wrap(Ctx&);
 void launch_halo_pack(Ctx&, int buffer);
@@ -142,6 +147,7 @@ struct Ctx {
   double* halo[4] = {};        // send-down, send-up, recv-from-below, recv-from-above
   size_t halo_doubles = 0;
   double* phi_halo[4] = {};
+  double* stage[MAXL] = {};    // in-place slabs: first/last plane of the new state, [27][2][plane]
   // distributed tridiagonal (slab contexts)
   int slab_row_a = 0, slab_m = 0;  // first unknown row (local plane) and number of unknown rows
   double* slab_u = nullptr;        // u = A^-1 e_1, [slab_m][modes]

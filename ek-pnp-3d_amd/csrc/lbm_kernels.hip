@@ -226,9 +226,9 @@ __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(
     // non-temporal: the populations written here are not read again before the next step
     // (+1 % on cfg3, profiles/r01_sweep_libs.log); EKPNP_PLAIN_STORES builds the A/B partner
 #ifdef EKPNP_PLAIN_STORES
-    if (act) dst[(long long)d * a.dstride + orow] = v;
+    if (act) dst[(long long)d * a.dstrideB + orow] = v;
 #else
-    if (act) __builtin_nontemporal_store(v, dst + (long long)d * a.dstride + orow);
+    if (act) __builtin_nontemporal_store(v, dst + (long long)d * a.dstrideB + orow);
 #endif
   };
   if (lat == 0) {
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int fi
         constexpr int sgn = (ex_of(d) > 0 || d == 3) ? 1 : (ex_of(d) < 0 ? -1 : 0);  // LBM.cu:1902-1927
         if constexpr (sgn != 0) v = v + sgn * (a.uw_multi * w_of(d));
       }
-      dst[(long long)d * a.dstride + orow] = v;
+      dst[(long long)d * a.dstrideB + orow] = v;
     });
   }
   // ions and temperature collide on the wall like anywhere else (their post-collision values
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int fi
       double* __restrict__ dst = a.B[lat];
       auto store = [&](auto ic, double v) {
         constexpr int d = decltype(ic)::value;
-        dst[(long long)d * a.dstride + orow] = v;
+        dst[(long long)d * a.dstrideB + orow] = v;
       };
       const double k = a.mob[lat];
       collide_scalar(a, g, ms[lat - 1], ux + k * Ex, uy + k * Ey, uz + k * Ez, a.wp[lat], a.wm[lat], store);
@@ -432,6 +432,35 @@ __global__ void k_halo_pack(const double* p0, const double* p1, const double* p2
     const double* p = pp[l];
     send_up[((long long)l * 9 + k) * plane + i] = p[(long long)up_dir(k) * dstride + (long long)nzl * plane + i];
     send_dn[((long long)l * 9 + k) * plane + i] = p[(long long)dn_dir(k) * dstride + plane + i];
+  }
+}
+
+// In-place slabs: the slab's first and last plane are collided into a 2-plane staging buffer
+// [27][2][ny][nx] per lattice (they must exist before the ordered sweep of the planes in between
+// may start, so that the halo exchange can overlap it); the halo is packed from there and the
+// two planes are copied into the lattice after the sweep.
+__global__ void k_halo_pack_stage(const double* s0, const double* s1, const double* s2, const double* s3, int nl, long long plane,
+                                  double* send_dn, double* send_up) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plane) return;
+  const int k = blockIdx.y;
+  const double* ss[MAXL] = {s0, s1, s2, s3};
+  for (int l = 0; l < nl; ++l) {
+    send_up[((long long)l * 9 + k) * plane + i] = ss[l][((long long)up_dir(k) * 2 + 1) * plane + i];  // last plane
+    send_dn[((long long)l * 9 + k) * plane + i] = ss[l][((long long)dn_dir(k) * 2 + 0) * plane + i];  // first plane
+  }
+}
+
+__global__ void k_unstage(double* p0, double* p1, double* p2, double* p3, const double* s0, const double* s1, const double* s2,
+                          const double* s3, int nl, long long plane, long long dstride, int nzl) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plane) return;
+  const int d = blockIdx.y;
+  double* pp[MAXL] = {p0, p1, p2, p3};
+  const double* ss[MAXL] = {s0, s1, s2, s3};
+  for (int l = 0; l < nl; ++l) {
+    pp[l][(long long)d * dstride + plane + i] = ss[l][((long long)d * 2 + 0) * plane + i];
+    pp[l][(long long)d * dstride + (long long)nzl * plane + i] = ss[l][((long long)d * 2 + 1) * plane + i];
   }
 }
 
@@ -503,7 +532,7 @@ __global__ void k_init_equilibrium(KArgs a) {
     equilibrium(a, m, ux + k * Ex, uy + k * Ey, uz + k * Ez, eq);
     double* dst = a.B[lat];
 #pragma unroll
-    for (int d = 0; d < Q; ++d) dst[(long long)d * a.dstride + o] = eq[d];
+    for (int d = 0; d < Q; ++d) dst[(long long)d * a.dstrideB + o] = eq[d];
   });
 }
 
@@ -555,8 +584,9 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
     hipLaunchKernelGGL((k_collide_bulk<NL, true>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
 }
 
-void launch_collide_bulk(Ctx& c, int zl_begin, int zl_end) {
-  KArgs a = c.kargs();
+void launch_collide_bulk(Ctx& c, int zl_begin, int zl_end) { launch_collide_bulk(c, c.kargs(), zl_begin, zl_end); }
+
+void launch_collide_bulk(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
   switch (c.p.n_lattices) {
     case 1: bulk_dispatch<1>(c, a, zl_begin, zl_end); break;
     case 3: bulk_dispatch<3>(c, a, zl_begin, zl_end); break;
@@ -574,7 +604,10 @@ static void wall_dispatch(Ctx& c, const KArgs& a, int first_wall, int nwalls, hi
 }
 
 void launch_collide_walls(Ctx& c, hipStream_t stream, bool want_lower, bool want_upper) {
-  KArgs a = c.kargs();
+  launch_collide_walls(c, c.kargs(), stream, want_lower, want_upper);
+}
+
+void launch_collide_walls(Ctx& c, const KArgs& a, hipStream_t stream, bool want_lower, bool want_upper) {
   const bool lower = want_lower && c.z0 == 0, upper = want_upper && c.z0 + c.nzl == c.p.nz;
   if (!lower && !upper) return;
   const int first_wall = lower ? 0 : 1, nwalls = (lower && upper) ? 2 : 1;
@@ -599,10 +632,23 @@ void launch_halo_pack(Ctx& c, int buffer) {
 }
 
 void launch_halo_unpack(Ctx& c) {
-  double** p = c.pop[c.cur];
+  double* p[MAXL] = {c.cur_base(0), c.cur_base(1), c.cur_base(2), c.cur_base(3)};
   dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
-  hipLaunchKernelGGL(k_halo_unpack, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane,
-                     (long long)(c.nzl + 2) * (long long)c.plane, c.nzl, c.halo[2], c.halo[3]);
+  hipLaunchKernelGGL(k_halo_unpack, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane, c.dstride(), c.nzl,
+                     c.halo[2], c.halo[3]);
+}
+
+void launch_halo_pack_stage(Ctx& c) {
+  dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
+  hipLaunchKernelGGL(k_halo_pack_stage, g, b, 0, c.stream, c.stage[0], c.stage[1], c.stage[2], c.stage[3], c.p.n_lattices,
+                     (long long)c.plane, c.halo[0], c.halo[1]);
+}
+
+void launch_unstage(Ctx& c) {
+  double* p[MAXL] = {c.cur_base(0), c.cur_base(1), c.cur_base(2), c.cur_base(3)};
+  dim3 g((unsigned)((c.plane + 255) / 256), Q), b(256);
+  hipLaunchKernelGGL(k_unstage, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.stage[0], c.stage[1], c.stage[2], c.stage[3],
+                     c.p.n_lattices, (long long)c.plane, c.dstride(), c.nzl);
 }
 
 }  // namespace ekpnp

@@ -64,7 +64,7 @@ typedef struct ekpnp_params {
                             /* each sweep writes the lattice shifted by min(nz/4,64)+1      */
                             /* planes in z and the shift direction alternates: 2 x 216 N    */
                             /* -> ~1.13 x 216 N bytes of populations per lattice at nz=512, */
-                            /* same results bit for bit (single-slab contexts only)         */
+                            /* same results bit for bit                                     */
   double Lx, Ly, Lz;        /* LBM.h:40-42; Lx=nx*dx, Ly=ny*dy, Lz=(nz-1)*dz    */
   double dx, dy, dz;        /* LBM.h:43-45                                      */
   double CFL;               /* LBM.h:51                                         */

@@ -435,12 +435,13 @@ def test_in_place_mode_is_bitwise_the_two_buffer_mode(pkg, O, shape):
     assert mem[1] < mem[0]
 
 
-def test_in_place_mode_vs_oracle_and_rejected_on_slabs(pkg, O):
+def test_in_place_mode_vs_oracle(pkg, O):
     po = O.default_params(20, 8, 140)
     po.pb_iterations = 10
     po.in_place = 1
     res = _run_pair(pkg, O, po, [1, 2, 9])
     _assert_all(res)
     p = _mirror(pkg, po)
+    p.in_place = 2
     with pytest.raises(pkg.EkpnpError):
-        pkg.Solver(p, rank=0, nranks=2)
+        pkg.Solver(p)

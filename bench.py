@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--ic", default="perturbed", choices=["perturbed", "uniform"])
     ap.add_argument("--pb-iterations", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-place", action="store_true", help="one population buffer (ekpnp_params.in_place): half the memory, N=1 only")
+    ap.add_argument("--in-place", action="store_true", help="one population buffer per lattice (ekpnp_params.in_place): 0.57x the memory of cfg3")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="transport of the N>1 path; gloo (host-staged) only to rehearse the multi-rank flow")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: put every rank on device 0")
@@ -173,7 +173,7 @@ def main():
     pkg = G.load_package()
 
     free_b, total_b = torch.cuda.mem_get_info()
-    wname, (nx, ny, nz), nl, use_in_place = parse_workload(args.workload, free_b, args.in_place and world == 1)
+    wname, (nx, ny, nz), nl, use_in_place = parse_workload(args.workload, free_b, args.in_place)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: WPS440
@@ -194,7 +194,7 @@ def main():
         p.chargeinf, p.TH, p.exf = 0.0, 0.0, 1e9
     if args.pb_iterations is not None:
         p.pb_iterations = args.pb_iterations
-    if use_in_place and world == 1:
+    if use_in_place:
         p.in_place = 1
 
     if world == 1:

@@ -183,6 +183,19 @@ class DistributedSlab:
     def synchronize(self):
         self.solver.synchronize()
 
+    # -- diagnostics (main.cu:211-222): every slab reduces its own planes, the ranks combine ----
+    def _allreduce(self, value: float, op):
+        t = self.torch.tensor([value], dtype=self.torch.float64, device="cpu" if self.tr.host_staged else "cuda")
+        self.tr.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def current(self) -> float:
+        """Wall current: only the slab holding the upper plate contributes (ekpnp_current)."""
+        return self._allreduce(self.solver.current(), self.tr.dist.ReduceOp.SUM)
+
+    def umax(self) -> float:
+        return self._allreduce(self.solver.umax(), self.tr.dist.ReduceOp.MAX)
+
 
 class LocalSlabGroup:
     """P slab contexts in one process on one device (tests): same kernels, same call order,
@@ -262,6 +275,12 @@ class LocalSlabGroup:
     def synchronize(self):
         for s in self.sol:
             s.synchronize()
+
+    def current(self) -> float:
+        return sum(s.current() for s in self.sol)
+
+    def umax(self) -> float:
+        return max(s.umax() for s in self.sol)
 
     # -- whole-lattice views ------------------------------------------------------------------
     def fields(self) -> dict:

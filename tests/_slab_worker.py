@@ -23,6 +23,7 @@ def main():
     nx, ny, nz = (int(v) for v in os.environ["EKPNP_SLAB_GRID"].split("x"))
     p = pkg.default_params(nx, ny, nz)
     p.pb_iterations = 12
+    p.in_place = int(os.environ.get("EKPNP_SLAB_IN_PLACE", "0"))
     run = DistributedSlab(p, rank, world, dist)
     run.initialization()
     s = run.solver
@@ -33,7 +34,7 @@ def main():
     run.init_equilibrium()
     run.step(6)
     run.synchronize()
-    np.savez(os.path.join(out, f"rank{rank}.npz"), z0=s.z0, **s.fields())
+    np.savez(os.path.join(out, f"rank{rank}.npz"), z0=s.z0, current=run.current(), umax=run.umax(), **s.fields())
     dist.barrier()
     run.close()
     dist.destroy_process_group()

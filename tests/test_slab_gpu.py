@@ -106,16 +106,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("shape,nprocs", [((16, 12, 16), 2), ((48, 20, 48), 4)])
-def test_processes_sharing_one_gpu_gloo(pkg, O, tmp_path, shape, nprocs):
+@pytest.mark.parametrize("shape,nprocs,in_place", [((16, 12, 16), 2, 0), ((48, 20, 48), 4, 0), ((24, 8, 48), 2, 1)])
+def test_processes_sharing_one_gpu_gloo(pkg, O, tmp_path, shape, nprocs, in_place):
     """The real multi-process path (DistributedSlab + RingTransport): 2 and 4 ranks sharing the one
     GPU of the box, launched like the driver launches bench.py."""
     p = pkg.default_params(*shape)
     p.pb_iterations = 12
     po = O.default_params(*shape)
     _, st, want = _single(pkg, O, p, lambda f: O.perturb_fields(po, f), 6)
+    with pkg.Solver(p) as ref:  # diagnostics of the single-context result
+        ref.set_fields(want)
+        want_current, want_umax = ref.current(), ref.umax()
     np.savez(tmp_path / "start.npz", **st)
-    env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_GRID="x".join(map(str, shape)), OMP_NUM_THREADS="1",
+    env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_IN_PLACE=str(in_place), EKPNP_SLAB_GRID="x".join(map(str, shape)), OMP_NUM_THREADS="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nprocs}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_slab_worker.py")]
@@ -125,3 +128,6 @@ def test_processes_sharing_one_gpu_gloo(pkg, O, tmp_path, shape, nprocs):
     got = {k: np.concatenate([d[k] for d in parts], axis=0) for k in O.FIELDS}
     err = O.rel_l2(got, want)
     assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err
+    for d in parts:  # every rank holds the combined diagnostics
+        assert abs(float(d["current"]) - want_current) <= 1e-9 * abs(want_current)
+        assert abs(float(d["umax"]) - want_umax) <= 1e-6 * abs(want_umax) + 1e-30

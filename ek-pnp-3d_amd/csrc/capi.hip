@@ -158,7 +158,7 @@ static int validate(const ekpnp_params* p, int rank, int nranks, std::string& er
   return EKPNP_OK;
 }
 
-static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** out) {
+static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, ekpnp_ctx** out) {
   if (!out) { g_create_err = "out is NULL"; return EKPNP_ERR_INVALID; }
   *out = nullptr;
   int rc = validate(p, rank, nranks, g_create_err);
@@ -168,6 +168,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   Ctx& c = h->c;
   c.p = *p;
   c.rank = rank; c.nranks = nranks;
+  c.slab = slab;
   c.nzl = p->nz / nranks;
   c.z0 = rank * c.nzl;
   // row pitch of the half spectrum: NX/2+1 complex, padded to a multiple of 8 (128 bytes) so that
@@ -197,7 +198,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
     for (int l = 0; l < p->n_lattices; ++l)
       if ((rc = dev_alloc(c, (void**)&c.pop[b][l], popbytes))) return bail(rc);
-  if (c.inplace && nranks > 1)
+  if (c.inplace && slab)
     for (int l = 0; l < p->n_lattices; ++l)
       if ((rc = dev_alloc(c, (void**)&c.stage[l], (size_t)Q * 2 * c.plane * sizeof(double)))) return bail(rc);
   for (int i = 0; i < EKPNP_NFIELDS; ++i) {
@@ -209,10 +210,10 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   if ((rc = dev_alloc(c, (void**)&c.spec, (size_t)c.nzl * p->ny * c.nxh * sizeof(double2)))) return bail(rc);
   if (hipMemsetAsync(c.spec, 0, (size_t)c.nzl * p->ny * c.nxh * sizeof(double2), c.stream) != hipSuccess) { c.err = "hipMemsetAsync failed"; return bail(EKPNP_ERR_HIP); }
   const size_t nmodes = (size_t)p->ny * c.nxh;
-  const size_t cprime_rows = nranks == 1 ? (size_t)p->nz : (size_t)c.nzl + 2;
+  const size_t cprime_rows = !slab ? (size_t)p->nz : (size_t)c.nzl + 2;
   if ((rc = dev_alloc(c, (void**)&c.cprime, cprime_rows * nmodes * sizeof(double)))) return bail(rc);
   c.halo_doubles = (size_t)p->n_lattices * 9 * c.plane;
-  if (nranks > 1) {
+  if (slab) {
     if (nranks > 16) { c.err = "at most 16 z slabs"; return bail(EKPNP_ERR_INVALID); }
     for (int k = 0; k < 4; ++k) {
       if ((rc = dev_alloc(c, (void**)&c.halo[k], c.halo_doubles * sizeof(double)))) return bail(rc);
@@ -249,8 +250,10 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** 
   return EKPNP_OK;
 }
 
-extern "C" int ekpnp_create(const ekpnp_params* p, ekpnp_ctx** out) { return create_impl(p, 0, 1, out); }
-extern "C" int ekpnp_create_slab(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** out) { return create_impl(p, rank, nranks, out); }
+extern "C" int ekpnp_create(const ekpnp_params* p, ekpnp_ctx** out) { return create_impl(p, 0, 1, false, out); }
+// nranks == 1 is allowed: one slab whose z neighbours are itself (the ring closes on the same
+// rank), driven through the same split calls - the full multi-rank code path on a single GPU.
+extern "C" int ekpnp_create_slab(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** out) { return create_impl(p, rank, nranks, true, out); }
 
 extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (!ctx) return EKPNP_ERR_INVALID;
@@ -380,7 +383,7 @@ static int poisson_single(Ctx& c) {
 
 extern "C" int ekpnp_fast_poisson(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks != 1) return fail(c, "ekpnp_fast_poisson on a slab context: use ekpnp_poisson_stage1/2/3 with the halo transport");
+  if (c.slab) return fail(c, "ekpnp_fast_poisson on a slab context: use ekpnp_poisson_stage1/2/3 with the halo transport");
   return poisson_single(c);
 }
 
@@ -427,7 +430,7 @@ extern "C" int ekpnp_pbe_end(ekpnp_ctx* ctx) {  // LBM.cu:107-108
 
 extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks != 1) return fail(c, "ekpnp_initialization on a slab context: drive ekpnp_init_fields / ekpnp_pbe_* and the Poisson stages through the slab host");
+  if (c.slab) return fail(c, "ekpnp_initialization on a slab context: drive ekpnp_init_fields / ekpnp_pbe_* and the Poisson stages through the slab host");
   int rc = ekpnp_init_fields(ctx);
   if (rc == EKPNP_OK) rc = ekpnp_pbe_begin(ctx);
   for (int i = 0; rc == EKPNP_OK && i < c.p.pb_iterations; ++i) {  // LBM.cu:89-106
@@ -450,7 +453,7 @@ extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
 //    (NZ > ~180 at the default spacing); omega = min(PB_omega, 1.6/(1 + A)) is used.
 extern "C" int ekpnp_initialization_converged(ekpnp_ctx* ctx, double rel_tol, int max_sweeps, int* sweeps, double* residual) {
   NEEDCTX(ctx);
-  if (c.nranks != 1) return fail(c, "ekpnp_initialization_converged is implemented for single-slab contexts");
+  if (c.slab) return fail(c, "ekpnp_initialization_converged is implemented for single-slab contexts");
   if (max_sweeps < 0) return fail(c, "max_sweeps < 0");
   double omega = c.p.PB_omega;
   if (c.p.chargeinf > 0.0) {
@@ -554,7 +557,7 @@ static void finish_collide(Ctx& c) {
 extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
   NEEDCTX(ctx);
   (void)t;  // the reference passes t but never uses it (LBM.cu:483-1846)
-  if (c.nranks != 1) return fail(c, "slab context: use ekpnp_collide_boundary_planes/interior_planes + halo transport");
+  if (c.slab) return fail(c, "slab context: use ekpnp_collide_boundary_planes/interior_planes + halo transport");
   // (running the two wall planes on a second stream beside the bulk kernel was measured: no gain,
   // the bulk kernel already saturates HBM and merely stretches - profiles/r01_bench_after_tuning.log)
   const int zb = bulk_begin(c), ze = bulk_end(c);
@@ -598,7 +601,7 @@ static int one_step(ekpnp_ctx* ctx) {  // main.cu:189-200
 // into a hipGraph and replayed; the arithmetic and its order are exactly the eager ones.
 static bool graph_wanted(const Ctx& c, int nsteps) {
   static const bool off = std::getenv("EKPNP_NO_GRAPH") != nullptr;
-  return !off && !c.graph_failed && !c.timing && !c.streamed_state && nsteps >= 4 && c.nranks == 1 &&
+  return !off && !c.graph_failed && !c.timing && !c.streamed_state && nsteps >= 4 && !c.slab &&
          c.nloc <= (size_t)4 * 1024 * 1024;  // beyond ~4 M nodes a step is >1 ms of kernels: nothing to gain
 }
 
@@ -633,7 +636,7 @@ static int capture_two_steps(ekpnp_ctx* ctx) {
 extern "C" int ekpnp_step(ekpnp_ctx* ctx, int nsteps) {
   NEEDCTX(ctx);
   if (nsteps < 0) return fail(c, "nsteps < 0");
-  if (c.nranks != 1) return fail(c, "slab context: drive the split calls through the slab host");
+  if (c.slab) return fail(c, "slab context: drive the split calls through the slab host");
   int i = 0;
   if (c.streamed_state && nsteps > 0) {  // the first step after init_equilibrium does not pull
     int rc = one_step(ctx);
@@ -692,7 +695,7 @@ extern "C" int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* 
 extern "C" int ekpnp_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, size_t* n) {
   NEEDCTX(ctx);
   if (which < 0 || which > 3 || !dptr || !n) return fail(c, "bad halo buffer id");
-  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
   *dptr = c.halo[which];
   *n = c.halo_doubles;
   return EKPNP_OK;
@@ -701,7 +704,7 @@ extern "C" int ekpnp_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, size_
 extern "C" int ekpnp_phi_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, size_t* n) {
   NEEDCTX(ctx);
   if (which < 0 || which > 3 || !dptr || !n) return fail(c, "bad halo buffer id");
-  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
   *dptr = c.phi_halo[which];
   *n = c.plane;
   return EKPNP_OK;
@@ -709,7 +712,7 @@ extern "C" int ekpnp_phi_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, s
 
 extern "C" int ekpnp_halo_pack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
   if (c.inplace) {
     if (c.collide_phase != 1) return fail(c, "in-place slab: ekpnp_halo_pack belongs between the boundary and the interior call");
     launch_halo_pack_stage(c);
@@ -723,7 +726,7 @@ extern "C" int ekpnp_halo_pack(ekpnp_ctx* ctx) {
 
 extern "C" int ekpnp_halo_unpack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
   if (c.collide_phase != 0) return fail(c, "ekpnp_halo_unpack before ekpnp_collide_interior_planes");
   launch_halo_unpack(c);
   HIPCHK(c, hipGetLastError());
@@ -732,7 +735,7 @@ extern "C" int ekpnp_halo_unpack(ekpnp_ctx* ctx) {
 
 extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_stream_collide_save");
+  if (!c.slab) return fail(c, "single-slab context: use ekpnp_stream_collide_save");
   if (c.collide_phase != 0) return fail(c, "ekpnp_collide_boundary_planes called twice");
   KArgs lo = c.kargs(), hi = lo;
   if (c.inplace) {
@@ -778,7 +781,7 @@ extern "C" int ekpnp_advance_time(ekpnp_ctx* ctx) {
 
 extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+  if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
   FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.work, (hipfftDoubleComplex*)c.spec));
@@ -789,7 +792,7 @@ extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
 
 extern "C" int ekpnp_poisson_edge_buffer(ekpnp_ctx* ctx, int gathered, double** dptr, size_t* n) {
   NEEDCTX(ctx);
-  if (c.nranks == 1 || !dptr || !n) return fail(c, "no edge buffers on a single-slab context");
+  if (!c.slab || !dptr || !n) return fail(c, "no edge buffers on a single-slab context");
   const size_t per_rank = 4 * (size_t)c.p.ny * c.nxh;
   *dptr = gathered ? c.edge_all : c.edge_local;
   *n = gathered ? per_rank * c.nranks : per_rank;
@@ -798,7 +801,7 @@ extern "C" int ekpnp_poisson_edge_buffer(ekpnp_ctx* ctx, int gathered, double** 
 
 extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+  if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   launch_slab_reduce_correct(c);
   FFTCHK(c, hipfftExecZ2D(c.plan_inv, (hipfftDoubleComplex*)c.spec, c.work));
   HIPCHK(c, hipGetLastError());
@@ -807,7 +810,7 @@ extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) {
 
 extern "C" int ekpnp_phi_halo_pack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks == 1) return fail(c, "no halo buffers on a single-slab context");
+  if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
   launch_phi_halo_pack(c);
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;
@@ -815,7 +818,7 @@ extern "C" int ekpnp_phi_halo_pack(ekpnp_ctx* ctx) {
 
 extern "C" int ekpnp_poisson_stage3(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.nranks == 1) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+  if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   launch_phi_efield(c);
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;

@@ -114,6 +114,7 @@ void launch_max_abs_diff(Ctx&, const double* p, const double* q, double* scratch
 struct Ctx {
   ekpnp_params p{};
   int rank = 0, nranks = 1;
+  bool slab = false;           // created by ekpnp_create_slab: driven through the split calls + a transport
   int nzl = 0, z0 = 0, nxh = 0;
   size_t plane = 0, nloc = 0;
   hipStream_t stream = nullptr;

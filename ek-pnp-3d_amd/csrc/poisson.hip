@@ -293,10 +293,10 @@ __global__ void k_phi_halo_pack(PArgs a, double* __restrict__ send_dn, double* _
 void build_cprime(Ctx& c) {
   const int nm = c.p.ny * c.nxh;
   // single context: rows 1..nz-2 of the global system; slab: rows 1..nzl of a local block
-  const int rows_nz = c.nranks == 1 ? c.p.nz : c.nzl + 2;
+  const int rows_nz = !c.slab ? c.p.nz : c.nzl + 2;
   hipLaunchKernelGGL(k_build_cprime, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.p.nx, c.p.ny, rows_nz, c.nxh, c.p.Lx,
                      c.p.Ly, c.p.dz);
-  if (c.nranks > 1) {
+  if (c.slab) {
     const bool edge_rank = (c.rank == 0 || c.rank == c.nranks - 1);
     hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.slab_m, nm, c.slab_u,
                        edge_rank ? c.u1um[0] : c.u1um[1]);

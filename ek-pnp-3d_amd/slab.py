@@ -124,7 +124,7 @@ class DistributedSlab:
         self.torch = torch
         self.p = params.copy()
         self.rank, self.world = rank, world
-        self.solver = Solver(params, rank, world)
+        self.solver = Solver(params, rank, world, slab=True)
         self.stream = torch.cuda.Stream()
         self.solver.set_stream(self.stream.cuda_stream)
         self.buf = _SlabBuffers(self.solver)
@@ -208,7 +208,7 @@ class LocalSlabGroup:
         self.p = params.copy()
         self.n = nslabs
         self.stream = torch.cuda.Stream()
-        self.sol = [Solver(params, r, nslabs) for r in range(nslabs)]
+        self.sol = [Solver(params, r, nslabs, slab=True) for r in range(nslabs)]
         for s in self.sol:
             s.set_stream(self.stream.cuda_stream)
         self.buf = [_SlabBuffers(s) for s in self.sol]

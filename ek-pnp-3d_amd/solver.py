@@ -165,11 +165,11 @@ def compute_parameters(p: Params) -> dict:
 class Solver:
     """One EK-PNP simulation on the current HIP device (or one z slab of it)."""
 
-    def __init__(self, params: Params, rank: int = 0, nranks: int = 1):
+    def __init__(self, params: Params, rank: int = 0, nranks: int = 1, slab: bool = False):
         self._L = load_library()
         self.p = params.copy()
         self._h = C.c_void_p()
-        if nranks == 1:
+        if nranks == 1 and not slab:
             rc = self._L.ekpnp_create(C.byref(self.p), C.byref(self._h))
         else:
             rc = self._L.ekpnp_create_slab(C.byref(self.p), rank, nranks, C.byref(self._h))

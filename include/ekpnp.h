@@ -99,7 +99,8 @@ int ekpnp_create(const ekpnp_params* p, ekpnp_ctx** out);
 /* z-slab variant (no reference counterpart): rank `rank` of
  * `nranks` owns planes [rank*nz/nranks, (rank+1)*nz/nranks).  nz % nranks must
  * be 0 and every slab needs >= 4 planes.  Halo transport is the caller's job,
- * through ekpnp_halo_* below. */
+ * through ekpnp_halo_* below.  nranks == 1 is allowed (the ring closes on the same
+ * rank): the whole multi-rank call sequence on one GPU. */
 int ekpnp_create_slab(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** out);
 
 /* Replaces main.cu:264-290 (cudaFree / cufftDestroy / cudaDeviceReset). */

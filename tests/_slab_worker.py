@@ -13,9 +13,12 @@ import __graft_entry__ as G  # noqa: E402
 
 
 def main():
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
+    if os.environ.get("EKPNP_SLAB_BACKEND", "gloo") == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     pkg = G.load_package()
     from ek_pnp_3d_amd.slab import DistributedSlab
 

@@ -25,7 +25,8 @@ def _single(pkg, O, p, start, steps):
         return init, st, s.fields()
 
 
-@pytest.mark.parametrize("shape,nslabs", [((16, 12, 16), 2), ((20, 6, 24), 3), ((70, 5, 32), 4), ((16, 8, 64), 8), ((12, 6, 40), 2), ((10, 4, 16), 4), ((8, 4, 102), 3)])
+@pytest.mark.parametrize("shape,nslabs", [((16, 12, 16), 2), ((20, 6, 24), 3), ((70, 5, 32), 4), ((16, 8, 64), 8), ((12, 6, 40), 2), ((10, 4, 16), 4), ((8, 4, 102), 3),
+                                          ((18, 6, 21), 1)])
 def test_local_slab_group_equals_single_context(pkg, O, shape, nslabs):
     from ek_pnp_3d_amd.slab import LocalSlabGroup
 
@@ -106,10 +107,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("shape,nprocs,in_place", [((16, 12, 16), 2, 0), ((48, 20, 48), 4, 0), ((24, 8, 48), 2, 1)])
-def test_processes_sharing_one_gpu_gloo(pkg, O, tmp_path, shape, nprocs, in_place):
-    """The real multi-process path (DistributedSlab + RingTransport): 2 and 4 ranks sharing the one
-    GPU of the box, launched like the driver launches bench.py."""
+@pytest.mark.parametrize("shape,nprocs,in_place,backend", [((16, 12, 16), 2, 0, "gloo"), ((48, 20, 48), 4, 0, "gloo"),
+                                                          ((24, 8, 48), 2, 1, "gloo"), ((32, 16, 40), 1, 0, "nccl"),
+                                                          ((32, 16, 40), 1, 1, "nccl")])
+def test_processes_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_place, backend):
+    """The real multi-process path (DistributedSlab + RingTransport), launched like the driver
+    launches bench.py: 2 and 4 ranks sharing the one GPU of the box over gloo (host-staged), and
+    ONE rank over RCCL ("nccl"): a single slab whose ring neighbours are itself, so every halo,
+    all-gather and phi exchange of the multi-GPU step really goes through RCCL send/recv on
+    tensors aliasing the library's device buffers (RCCL refuses two ranks on one device)."""
     p = pkg.default_params(*shape)
     p.pb_iterations = 12
     po = O.default_params(*shape)
@@ -118,7 +124,7 @@ def test_processes_sharing_one_gpu_gloo(pkg, O, tmp_path, shape, nprocs, in_plac
         ref.set_fields(want)
         want_current, want_umax = ref.current(), ref.umax()
     np.savez(tmp_path / "start.npz", **st)
-    env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_IN_PLACE=str(in_place), EKPNP_SLAB_GRID="x".join(map(str, shape)), OMP_NUM_THREADS="1",
+    env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_IN_PLACE=str(in_place), EKPNP_SLAB_BACKEND=backend, EKPNP_SLAB_GRID="x".join(map(str, shape)), OMP_NUM_THREADS="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nprocs}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_slab_worker.py")]

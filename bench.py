@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="transport of the N>1 path; gloo (host-staged) only to rehearse the multi-rank flow")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: put every rank on device 0")
+    ap.add_argument("--force-slab", action="store_true",
+                    help="N=1 only: run the multi-rank code path (split calls + RCCL exchanges, the ring closing on the same rank)")
     args = ap.parse_args()
 
     import torch
@@ -175,16 +177,22 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info()
     wname, (nx, ny, nz), nl, use_in_place = parse_workload(args.workload, free_b, args.in_place)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_slab:
         import torch.distributed as dist  # noqa: WPS440
 
+        kw = {}
+        if "RANK" not in os.environ:  # plain `python bench.py --force-slab`
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            kw = {"init_method": f"tcp://127.0.0.1:{port}", "rank": 0, "world_size": 1}
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:
-            dist.init_process_group("gloo")
-        nz_global = nz * world  # weak scaling: one cfg-sized slab per GPU
-    else:
-        nz_global = nz
+            dist.init_process_group("gloo", **kw)
+    nz_global = nz * world  # weak scaling: one cfg-sized slab per GPU
 
     p = pkg.default_params(nx, ny, nz_global)
     p.n_lattices = nl
@@ -197,7 +205,7 @@ def main():
     if use_in_place:
         p.in_place = 1
 
-    if world == 1:
+    if dist is None:
         sol = pkg.Solver(p)
         runner = sol
     else:
@@ -283,7 +291,8 @@ def main():
             "config": {
                 "workload": f"{wname}: {nx}x{ny}x{nz_global} D3Q27 x{nl} lattices"
                 + (" + spectral Poisson" if nl > 1 else "")
-                + (f", z-slabs of {nz} planes over {world} GPUs" if world > 1 else ""),
+                + (f", z-slabs of {nz} planes over {world} GPUs" if world > 1 else "")
+                + (", multi-rank code path on one rank (RCCL ring to itself)" if world == 1 and dist is not None else ""),
                 "grid": [nx, ny, nz_global],
                 "lattices": nl,
                 "in_place": bool(p.in_place),

@@ -133,6 +133,16 @@ def main(outdir):
             g3[f"step{m}_{k}"] = f[k]
     np.savez_compressed(os.path.join(outdir, "ref_g3_full.npz"), **g3)
 
+    # ---- G7: moving upper wall (uw = 1e-3, no ions, no buoyancy): the reference's wall-velocity terms
+    # including the "+multis on direction 3 only" of LBM.cu:1904; rho and u do not see phi here.
+    run("--set", "uw=1e-3", "--set", "chargeinf=0", "--set", "Ra=0", "--set", "TH=0", "init", "g7", "1", "100", "2000")
+    g7 = {"marks": np.array([1, 100, 2000])}
+    for m in (1, 100, 2000):
+        f = read_bin(os.path.join(tmp, f"g7_step{m}.bin"))
+        for k in ("rho", "ux", "uy", "uz"):
+            g7[f"step{m}_{k}"] = f[k]
+    np.savez_compressed(os.path.join(outdir, "ref_g7_full.npz"), **g7)
+
     # ---- G5
     rng = np.random.default_rng(5)
     f5 = {k: np.zeros(SHAPE) for k in O.FIELDS}

@@ -165,6 +165,15 @@ def main(src, dst):
             out[f"step{m}_{k}"] = a[:, YSEL, :].copy()
     np.savez_compressed(os.path.join(dst, "ref_g3.npz"), **out)
 
+    # ---- G7 (moving wall; rho, u do not depend on phi) -----------------------------------------
+    if os.path.exists(os.path.join(src, "ref_g7_full.npz")):
+        g7 = np.load(os.path.join(src, "ref_g7_full.npz"))
+        out = {"marks": g7["marks"]}
+        for m in g7["marks"]:
+            for k in ("rho", "ux", "uy", "uz"):
+                out[f"step{m}_{k}"] = g7[f"step{m}_{k}"][:, YSEL, :].copy()
+        np.savez_compressed(os.path.join(dst, "ref_g7.npz"), **out)
+
     # ---- G5 ------------------------------------------------------------------------------
     o = O.Oracle(p)
     o.set_fields({k: g5["input_" + k] for k in O.FIELDS})

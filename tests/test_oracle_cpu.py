@@ -235,6 +235,26 @@ def test_golden_G3_body_force_channel(O):
         assert err["rho"] < 1e-12 and err["u"] < 1e-9, (mark, err)
 
 
+def test_golden_G7_moving_wall(O):
+    """uw = 1e-3 on the upper plate (LBM.cu:1896-1927, including "+ multis" on direction 3 only),
+    chargeinf = 0, Ra = 0, TH = 0: rho and u are free of the DC leak."""
+    g = _need("ref_g7.npz")
+    p = _ref_grid(O)
+    p.uw, p.chargeinf, p.Ra, p.TH = 1e-3, 0.0, 0.0, 0.0
+    o = O.Oracle(p)
+    o.initialization()
+    o.init_equilibrium()
+    full = os.environ.get("EKPNP_LONG_TESTS") == "1"
+    done = 0
+    for mark in (int(m) for m in g["marks"] if full or m <= 100):
+        o.step(mark - done)
+        done = mark
+        f = {k: o.field(k)[:, [0, 3, 5], :] for k in ("rho", "ux", "uy", "uz")}
+        err = O.rel_l2(f, {k: g[f"step{mark}_{k}"] for k in f}, {"rho": ["rho"], "u": ["ux", "uy", "uz"]})
+        assert err["rho"] < 1e-12 and err["u"] < 1e-8, (mark, err)
+    assert np.abs(g["step100_uy"]).max() > 0  # the direction-3 quirk drives a y velocity at the wall
+
+
 def test_golden_G5_poisson_alone(O):
     g = _need("ref_g5.npz")
     p = _ref_grid(O)

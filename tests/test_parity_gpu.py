@@ -350,6 +350,23 @@ def test_golden_G3_hip_vs_reference_kernels_direct(pkg, O):
             assert err["rho"] < 1e-12 and err["u"] < 1e-8, (mark, err)
 
 
+def test_golden_G7_hip_moving_wall_vs_reference_kernels_direct(pkg, O):
+    g = _need("ref_g7.npz")
+    po = _ref_grid(O)
+    po.uw, po.chargeinf, po.Ra, po.TH = 1e-3, 0.0, 0.0, 0.0
+    with pkg.Solver(_mirror(pkg, po)) as s:
+        s.initialization()
+        s.init_equilibrium()
+        done = 0
+        for mark in (int(m) for m in g["marks"]):
+            s.step(mark - done)
+            done = mark
+            f = {k: s.get_field(k)[:, [0, 3, 5], :] for k in ("rho", "ux", "uy", "uz")}
+            err = O.rel_l2(f, {k: g[f"step{mark}_{k}"] for k in f}, {"rho": ["rho"], "u": ["ux", "uy", "uz"]})
+            _REPORT.append({"test": "golden_G7_direct", "mark": str(mark), "rel_l2": err})
+            assert err["rho"] < 1e-12 and err["u"] < 1e-8, (mark, err)
+
+
 def test_golden_G5_hip_poisson_vs_reference_modulo_dc_leak(pkg, O):
     """HIP phi == reference phi minus the reference's measured DC constant, to rounding."""
     g = _need("ref_g5.npz")

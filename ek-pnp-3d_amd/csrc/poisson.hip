@@ -85,6 +85,51 @@ __global__ void k_tridiag(PArgs a) {
   }
 }
 
+// Short channels (NZ - 2 <= 64 unknown rows, e.g. the reference's own 51 planes): the serial
+// sweeps above are a chain of ~2 NZ dependent loads per mode and dominate a step that is only
+// tens of microseconds long.  Here one wave64 owns one (kx,ky) mode, lane i holds row i + 1, and
+// the constant-coefficient system  x[i-1] + b x[i] + x[i+1] = r[i]  is solved by parallel cyclic
+// reduction in 6 shuffle steps (rows outside 1..NZ-2 act as identity rows).
+__global__ void __launch_bounds__(256) k_tridiag_pcr64(PArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int md = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long ms = (long long)a.ny * a.nxh;
+  if (md >= ms) return;  // wave-uniform
+  const int m = a.nz - 2;  // unknown rows, <= 64
+  const bool live = lane < m;
+  // b of this mode: cprime row 1 holds c'_1 = 1/b
+  const double bdiag = 1.0 / a.cprime[ms + md];
+  double2* s = a.spec + md + (long long)(lane + 1) * ms;
+  const double dz2 = a.dz * a.dz;
+  double lo = live && lane > 0 ? 1.0 : 0.0;      // coefficient of x[i - stride]
+  double up = live && lane < m - 1 ? 1.0 : 0.0;  // coefficient of x[i + stride]
+  double bd = live ? bdiag : 1.0;
+  double rr = 0.0, ri = 0.0;
+  if (live) {
+    const double2 r = *s;
+    rr = dz2 * r.x;
+    ri = dz2 * r.y;
+  }
+#pragma unroll
+  for (int st = 1; st < 64; st <<= 1) {
+    // neighbours' rows (identity rows outside the wave)
+    const bool hl = lane - st >= 0, hu = lane + st < 64;
+    double lo_l = __shfl_up(lo, st, 64), up_l = __shfl_up(up, st, 64), bd_l = __shfl_up(bd, st, 64);
+    double rr_l = __shfl_up(rr, st, 64), ri_l = __shfl_up(ri, st, 64);
+    double lo_u = __shfl_down(lo, st, 64), up_u = __shfl_down(up, st, 64), bd_u = __shfl_down(bd, st, 64);
+    double rr_u = __shfl_down(rr, st, 64), ri_u = __shfl_down(ri, st, 64);
+    if (!hl) { lo_l = 0.0; up_l = 0.0; bd_l = 1.0; rr_l = 0.0; ri_l = 0.0; }
+    if (!hu) { lo_u = 0.0; up_u = 0.0; bd_u = 1.0; rr_u = 0.0; ri_u = 0.0; }
+    const double al = -lo / bd_l, ga = -up / bd_u;
+    bd = bd + al * up_l + ga * lo_u;
+    rr = rr + al * rr_l + ga * rr_u;
+    ri = ri + al * ri_l + ga * ri_u;
+    lo = al * lo_l;
+    up = ga * up_u;
+  }
+  if (live) *s = make_double2(rr / bd, ri / bd);
+}
+
 // odd_extract + gpu_efield + gpu_bc fused (poisson.cu:191-204, 40-69): phi = ifft/(NX NY) on
 // interior planes, wall planes pinned to voltage/voltage2; E = central differences of phi,
 // periodic in x,y; Ez of a wall plane copies the neighbouring interior plane.
@@ -340,7 +385,10 @@ void launch_poisson_rhs(Ctx& c) {
 void launch_tridiag(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
-  hipLaunchKernelGGL(k_tridiag, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a);
+  if (c.p.nz - 2 <= 64)
+    hipLaunchKernelGGL(k_tridiag_pcr64, dim3((nm + 3) / 4), dim3(256), 0, c.stream, a);
+  else
+    hipLaunchKernelGGL(k_tridiag, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a);
 }
 
 void launch_phi_efield(Ctx& c) {

@@ -86,6 +86,10 @@ KArgs Ctx::kargs() const {
   for (int i = 0; i < EKPNP_NFIELDS; ++i) a.fld[i] = fld[i];
   a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
   a.nzl = nzl; a.z0 = z0;
+  // ghost planes are filled by the halo transport (slabs) or by k_ghost_wrap right after the sweep
+  // (in-place mode: the opposite wall plane of the old state may be overwritten by then); a plain
+  // two-buffer context needs neither: its wall nodes index the opposite wall plane
+  a.zwrap = (!slab && !inplace) ? 1 : 0;
   a.plane = (long long)plane;
   a.dstride = dstride();
   a.dstrideB = a.dstride;
@@ -581,7 +585,7 @@ extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
     launch_collide_walls(c, c.stream, !up, up);
   }
   finish_collide(c);
-  launch_ghost_wrap(c);  // z-periodic ghost loop of gpu_stream, LBM.cu:1972,1975
+  if (c.inplace) launch_ghost_wrap(c);  // z-periodic ghost loop of gpu_stream, LBM.cu:1972,1975 (by index otherwise)
   HIPCHK(c, hipGetLastError());
   return EKPNP_OK;
 }

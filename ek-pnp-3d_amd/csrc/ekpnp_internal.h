@@ -52,6 +52,7 @@ struct KArgs {
   double* fld[EKPNP_NFIELDS];  // [nzl][ny][nx]
   int nx, ny, nz;              // global lattice
   int nzl, z0;                 // owned planes and the global index of the first one
+  int zwrap;                   // 1: whole lattice in one two-buffer context, wall nodes wrap z by index
   long long plane;             // nx*ny
   long long dstride;           // direction stride of A: (nzl+2+shift)*plane
   long long dstrideB;          // direction stride of B (differs only when B is the 2-plane staging buffer)

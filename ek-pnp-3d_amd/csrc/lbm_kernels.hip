@@ -265,7 +265,13 @@ __device__ __forceinline__ void gather(const KArgs& a, const double* __restrict_
   static_for<0, Q, 1>([&](auto ic) {
     constexpr int d = decltype(ic)::value;
     constexpr int cx = PULL ? ex_of(d) : 0, cy = PULL ? ey_of(d) : 0, cz = PULL ? ez_of(d) : 0;
-    f[d] = src[(long long)d * a.dstride + ((long long)(zg - cz) * a.ny + ys[cy + 1]) * (long long)a.nx + xs[cx + 1]];
+    int zs = zg - cz;
+    if constexpr (cz != 0) {
+      // gpu_stream's z wrap (LBM.cu:1972,1975): with zwrap the wall nodes read the opposite wall
+      // plane directly instead of a ghost-plane copy of it
+      if (a.zwrap) zs = zs == 0 ? a.nzl : (zs == a.nzl + 1 ? 1 : zs);
+    }
+    f[d] = src[(long long)d * a.dstride + ((long long)zs * a.ny + ys[cy + 1]) * (long long)a.nx + xs[cx + 1]];
   });
 }
 

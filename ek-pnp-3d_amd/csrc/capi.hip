@@ -205,8 +205,14 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   if (c.inplace && slab)
     for (int l = 0; l < p->n_lattices; ++l)
       if ((rc = dev_alloc(c, (void**)&c.stage[l], (size_t)Q * 2 * c.plane * sizeof(double)))) return bail(rc);
+  // The 11 macroscopic arrays are equally sized (a power of two bytes on cfg2/cfg3) and are walked
+  // in lockstep by the kernels; identical placement modulo the HBM channel interleave makes all of
+  // their streams queue on the same channels.  Each owned array is therefore skewed by a different
+  // multiple of `skew` bytes inside a slightly larger allocation (EKPNP_FIELD_SKEW: tuning knob).
+  static const size_t skew = std::getenv("EKPNP_FIELD_SKEW") ? (size_t)std::atoll(std::getenv("EKPNP_FIELD_SKEW")) : 0;
   for (int i = 0; i < EKPNP_NFIELDS; ++i) {
-    if ((rc = dev_alloc(c, (void**)&c.fld[i], c.nloc * sizeof(double)))) return bail(rc);
+    if ((rc = dev_alloc(c, &c.fld_alloc[i], c.nloc * sizeof(double) + (size_t)EKPNP_NFIELDS * skew))) return bail(rc);
+    c.fld[i] = (double*)((char*)c.fld_alloc[i] + (size_t)i * skew);
     c.fld_owned[i] = true;
     if (hipMemsetAsync(c.fld[i], 0, c.nloc * sizeof(double), c.stream) != hipSuccess) { c.err = "hipMemsetAsync failed"; return bail(EKPNP_ERR_HIP); }
   }
@@ -269,7 +275,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   for (int l = 0; l < MAXL; ++l)
     if (c.stage[l]) (void)hipFree(c.stage[l]);
   for (int i = 0; i < EKPNP_NFIELDS; ++i)
-    if (c.fld[i] && c.fld_owned[i]) (void)hipFree(c.fld[i]);
+    if (c.fld_alloc[i] && c.fld_owned[i]) (void)hipFree(c.fld_alloc[i]);
   if (c.work) (void)hipFree(c.work);
   if (c.spec) (void)hipFree(c.spec);
   if (c.cprime) (void)hipFree(c.cprime);
@@ -317,7 +323,7 @@ extern "C" int ekpnp_bind_field(ekpnp_ctx* ctx, int id, double* dptr) {
   if (id < 0 || id >= EKPNP_NFIELDS || !dptr) return fail(c, "bad field id or NULL pointer");
   HIPCHK(c, hipStreamSynchronize(c.stream));
   HIPCHK(c, hipMemcpy(dptr, c.fld[id], c.nloc * sizeof(double), hipMemcpyDeviceToDevice));
-  if (c.fld_owned[id]) { (void)hipFree(c.fld[id]); c.bytes -= c.nloc * sizeof(double); }
+  if (c.fld_owned[id]) { (void)hipFree(c.fld_alloc[id]); c.fld_alloc[id] = nullptr; c.bytes -= c.nloc * sizeof(double); }
   c.fld[id] = dptr;
   c.fld_owned[id] = false;
   c.rhs_ready = false;

@@ -143,6 +143,7 @@ struct Ctx {
                                // false: pop[cur] holds post-collision populations (pull next)
   double* fld[EKPNP_NFIELDS] = {};
   bool fld_owned[EKPNP_NFIELDS] = {};
+  void* fld_alloc[EKPNP_NFIELDS] = {};  // what hipMalloc returned for an owned field (fld[i] is skewed into it)
   double* work = nullptr;
   double2* spec = nullptr;
   double* cprime = nullptr;

@@ -199,9 +199,14 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.zchunk = c.inplace ? (c.nzl / 4 < 1 ? 1 : c.nzl / 4 > 64 ? 64 : c.nzl / 4) : 0;
   c.shift = c.inplace ? c.zchunk + 1 : 0;
   const size_t popbytes = (size_t)Q * (c.nzl + 2 + c.shift) * c.plane * sizeof(double);
+  // the (up to) 8 population arrays are equally sized and walked in lockstep: skew them against
+  // each other like the macroscopic arrays below (EKPNP_POP_SKEW: tuning knob)
+  static const size_t pskew = std::getenv("EKPNP_POP_SKEW") ? (size_t)std::atoll(std::getenv("EKPNP_POP_SKEW")) : 0;
   for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
-    for (int l = 0; l < p->n_lattices; ++l)
-      if ((rc = dev_alloc(c, (void**)&c.pop[b][l], popbytes))) return bail(rc);
+    for (int l = 0; l < p->n_lattices; ++l) {
+      if ((rc = dev_alloc(c, &c.pop_alloc[b][l], popbytes + 8 * pskew))) return bail(rc);
+      c.pop[b][l] = (double*)((char*)c.pop_alloc[b][l] + (size_t)(b * MAXL + l) * pskew);
+    }
   if (c.inplace && slab)
     for (int l = 0; l < p->n_lattices; ++l)
       if ((rc = dev_alloc(c, (void**)&c.stage[l], (size_t)Q * 2 * c.plane * sizeof(double)))) return bail(rc);
@@ -209,7 +214,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   // in lockstep by the kernels; identical placement modulo the HBM channel interleave makes all of
   // their streams queue on the same channels.  Each owned array is therefore skewed by a different
   // multiple of `skew` bytes inside a slightly larger allocation (EKPNP_FIELD_SKEW: tuning knob).
-  static const size_t skew = std::getenv("EKPNP_FIELD_SKEW") ? (size_t)std::atoll(std::getenv("EKPNP_FIELD_SKEW")) : 0;
+  static const size_t skew = std::getenv("EKPNP_FIELD_SKEW") ? (size_t)std::atoll(std::getenv("EKPNP_FIELD_SKEW")) : 69888;
   for (int i = 0; i < EKPNP_NFIELDS; ++i) {
     if ((rc = dev_alloc(c, &c.fld_alloc[i], c.nloc * sizeof(double) + (size_t)EKPNP_NFIELDS * skew))) return bail(rc);
     c.fld[i] = (double*)((char*)c.fld_alloc[i] + (size_t)i * skew);
@@ -271,7 +276,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (c.stream) (void)hipStreamSynchronize(c.stream);
   for (int b = 0; b < 2; ++b)
     for (int l = 0; l < MAXL; ++l)
-      if (c.pop[b][l]) (void)hipFree(c.pop[b][l]);
+      if (c.pop_alloc[b][l]) (void)hipFree(c.pop_alloc[b][l]);
   for (int l = 0; l < MAXL; ++l)
     if (c.stage[l]) (void)hipFree(c.stage[l]);
   for (int i = 0; i < EKPNP_NFIELDS; ++i)

@@ -121,6 +121,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   double* pop[2][MAXL] = {};   // [buffer][lattice]; in-place mode uses pop[0] only
+  void* pop_alloc[2][MAXL] = {};  // what hipMalloc returned (pop[b][l] is skewed into it)
   int cur = 0;                 // A/B mode: buffer holding the current state.  In-place mode: the
                                // parity of the storage offset (0: lattice at +shift planes, the
                                // next sweep runs z-ascending and writes at offset 0; 1: mirror)

@@ -199,13 +199,12 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.zchunk = c.inplace ? (c.nzl / 4 < 1 ? 1 : c.nzl / 4 > 64 ? 64 : c.nzl / 4) : 0;
   c.shift = c.inplace ? c.zchunk + 1 : 0;
   const size_t popbytes = (size_t)Q * (c.nzl + 2 + c.shift) * c.plane * sizeof(double);
-  // the (up to) 8 population arrays are equally sized and walked in lockstep: skew them against
-  // each other like the macroscopic arrays below (EKPNP_POP_SKEW: tuning knob)
-  static const size_t pskew = std::getenv("EKPNP_POP_SKEW") ? (size_t)std::atoll(std::getenv("EKPNP_POP_SKEW")) : 0;
+  // (skewing the population arrays against each other like the macroscopic arrays below was
+  // measured too: -1.5 %, profiles/r01_sweep_skew.log - they stay where hipMalloc puts them)
   for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
     for (int l = 0; l < p->n_lattices; ++l) {
-      if ((rc = dev_alloc(c, &c.pop_alloc[b][l], popbytes + 8 * pskew))) return bail(rc);
-      c.pop[b][l] = (double*)((char*)c.pop_alloc[b][l] + (size_t)(b * MAXL + l) * pskew);
+      if ((rc = dev_alloc(c, &c.pop_alloc[b][l], popbytes))) return bail(rc);
+      c.pop[b][l] = (double*)c.pop_alloc[b][l];
     }
   if (c.inplace && slab)
     for (int l = 0; l < p->n_lattices; ++l)

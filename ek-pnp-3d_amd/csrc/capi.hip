@@ -213,7 +213,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   // in lockstep by the kernels; identical placement modulo the HBM channel interleave makes all of
   // their streams queue on the same channels.  Each owned array is therefore skewed by a different
   // multiple of `skew` bytes inside a slightly larger allocation (EKPNP_FIELD_SKEW: tuning knob).
-  static const size_t skew = std::getenv("EKPNP_FIELD_SKEW") ? (size_t)std::atoll(std::getenv("EKPNP_FIELD_SKEW")) : 69888;
+  static const size_t skew = std::getenv("EKPNP_FIELD_SKEW") ? (size_t)std::atoll(std::getenv("EKPNP_FIELD_SKEW")) : 4096;
   for (int i = 0; i < EKPNP_NFIELDS; ++i) {
     if ((rc = dev_alloc(c, &c.fld_alloc[i], c.nloc * sizeof(double) + (size_t)EKPNP_NFIELDS * skew))) return bail(rc);
     c.fld[i] = (double*)((char*)c.fld_alloc[i] + (size_t)i * skew);

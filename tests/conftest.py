@@ -16,7 +16,10 @@ def pytest_configure(config):
 def pkg():
     import __graft_entry__ as g
 
-    return g.load_package()
+    p = g.load_package()
+    if not os.path.exists(p.library_path()):  # fresh checkout: the in-tree .so files are git-ignored
+        g.build()
+    return p
 
 
 @pytest.fixture(scope="session")

@@ -91,8 +91,7 @@ KArgs Ctx::kargs() const {
   // two-buffer context needs neither: its wall nodes index the opposite wall plane
   a.zwrap = (!slab && !inplace) ? 1 : 0;
   a.plane = (long long)plane;
-  a.dstride = dstride();
-  a.dstrideB = a.dstride;
+  a.rowstride = (long long)rowstride;
   const double cs2 = p.cs_square, dt = p.dt;
   // relaxation rates, LBM.cu:488-495 (same expression order)
   const double omega_plus = 1.0 / (p.nu / cs2 / dt + 1.0 / 2.0) / dt;
@@ -181,6 +180,8 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.nxh = (p->nx / 2 + 1 + 7) / 8 * 8;
   c.plane = (size_t)p->nx * p->ny;
   c.nloc = c.plane * c.nzl;
+  c.rowstride = (size_t)((p->nx + 63) / 64) * TILE;
+  c.pplane = c.rowstride * p->ny;
   auto bail = [&](int code) {
     g_create_err = c.err;
     ekpnp_destroy(h);
@@ -198,7 +199,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.inplace = p->in_place != 0;
   c.zchunk = c.inplace ? (c.nzl / 4 < 1 ? 1 : c.nzl / 4 > 64 ? 64 : c.nzl / 4) : 0;
   c.shift = c.inplace ? c.zchunk + 1 : 0;
-  const size_t popbytes = (size_t)Q * (c.nzl + 2 + c.shift) * c.plane * sizeof(double);
+  const size_t popbytes = (size_t)(c.nzl + 2 + c.shift) * c.pplane * sizeof(double);
   // (skewing the population arrays against each other like the macroscopic arrays below was
   // measured too: -1.5 %, profiles/r01_sweep_skew.log - they stay where hipMalloc puts them)
   for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
@@ -208,7 +209,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
     }
   if (c.inplace && slab)
     for (int l = 0; l < p->n_lattices; ++l)
-      if ((rc = dev_alloc(c, (void**)&c.stage[l], (size_t)Q * 2 * c.plane * sizeof(double)))) return bail(rc);
+      if ((rc = dev_alloc(c, (void**)&c.stage[l], 2 * c.pplane * sizeof(double)))) return bail(rc);
   // The 11 macroscopic arrays are equally sized (a power of two bytes on cfg2/cfg3) and are walked
   // in lockstep by the kernels; identical placement modulo the HBM channel interleave makes all of
   // their streams queue on the same channels.  Each owned array is therefore skewed by a different
@@ -754,10 +755,9 @@ extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
   KArgs lo = c.kargs(), hi = lo;
   if (c.inplace) {
     // redirect the stores of plane zg = 1 / zg = nzl into the staging planes 0 / 1
-    lo.dstrideB = hi.dstrideB = 2 * (long long)c.plane;
     for (int l = 0; l < c.p.n_lattices; ++l) {
-      lo.B[l] = c.stage[l] - (ptrdiff_t)c.plane;                          // (d, zg=1)   -> stage[d][0]
-      hi.B[l] = c.stage[l] + (ptrdiff_t)c.plane - (ptrdiff_t)c.nzl * (ptrdiff_t)c.plane;  // (d, zg=nzl) -> stage[d][1]
+      lo.B[l] = c.stage[l] - (ptrdiff_t)c.pplane;                              // plane zg = 1   -> staging plane 0
+      hi.B[l] = c.stage[l] + (ptrdiff_t)c.pplane - (ptrdiff_t)c.nzl * (ptrdiff_t)c.pplane;  // plane zg = nzl -> staging plane 1
     }
   }
   launch_collide_walls(c, lo, c.stream, true, false);

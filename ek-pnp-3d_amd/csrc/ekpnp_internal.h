@@ -44,18 +44,26 @@ __host__ __device__ constexpr int dn_dir(int k) {
   return t[k];
 }
 
+// Population layout (one array per lattice): [zg][y][x/64][Q][64] - a TILE holds the 27 populations
+// of 64 consecutive x nodes (13.8 KB), a row is ceil(nx/64) tiles, plane zg = 0 / nzl+1 are the
+// ghost planes.  The bulk kernel's wave writes ONE contiguous tile and pulls from the tiles of 9
+// neighbour rows; with the direction-major layout [Q][zg][y][x] it touched 27 + 27 streams that
+// lie gigabytes apart (pure-copy ceiling of the two shapes on one box: 5.95 vs 5.48 TB/s,
+// profiles/r01_stream_probe_aosoa.log).  Lanes of the last tile beyond nx are never touched.
+constexpr int TILE = Q * 64;
+__host__ __device__ inline long long pop_xoff(int x) { return (long long)(x >> 6) * TILE + (x & 63); }
+
 // Everything a kernel needs, passed by value.
 struct KArgs {
-  // population buffers: [Q][nzl+2][ny][nx] per lattice, ghost plane below (zg=0) and above
+  // population buffers, tiled as above; B may also be the 2-plane staging buffer (same layout)
   const double* A[MAXL];
   double* B[MAXL];
   double* fld[EKPNP_NFIELDS];  // [nzl][ny][nx]
   int nx, ny, nz;              // global lattice
   int nzl, z0;                 // owned planes and the global index of the first one
   int zwrap;                   // 1: whole lattice in one two-buffer context, wall nodes wrap z by index
-  long long plane;             // nx*ny
-  long long dstride;           // direction stride of A: (nzl+2+shift)*plane
-  long long dstrideB;          // direction stride of B (differs only when B is the 2-plane staging buffer)
+  long long plane;             // nx*ny (macroscopic fields)
+  long long rowstride;         // doubles per population row: ceil(nx/64)*TILE
   // derived physics (host-side, in the reference's expression order, LBM.cu:488-495,1660-1661)
   double wp[MAXL], wm[MAXL];   // omega_plus*dt / omega_minus*dt per lattice
   double mob[MAXL];            // drift mobility: 0, K, Kn, 0
@@ -118,6 +126,7 @@ struct Ctx {
   bool slab = false;           // created by ekpnp_create_slab: driven through the split calls + a transport
   int nzl = 0, z0 = 0, nxh = 0;
   size_t plane = 0, nloc = 0;
+  size_t rowstride = 0, pplane = 0;  // doubles per population row / plane (tiled layout, ekpnp::TILE)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   double* pop[2][MAXL] = {};   // [buffer][lattice]; in-place mode uses pop[0] only
@@ -128,17 +137,15 @@ struct Ctx {
   bool inplace = false;
   int shift = 0;               // planes the lattice moves per sweep in in-place mode (0 in A/B mode)
   int zchunk = 0;              // planes per bulk launch in in-place mode (shift >= zchunk + 1)
-  // base pointer of lattice l's CURRENT state (plane zg = 0 is the ghost plane below) and the
-  // direction stride shared by all population addressing
+  // base pointer of lattice l's CURRENT state (plane zg = 0 is the ghost plane below)
   double* cur_base(int l) const {
     if (!inplace) return pop[cur][l];
-    return pop[0][l] ? pop[0][l] + (size_t)(cur == 0 ? shift : 0) * plane : nullptr;
+    return pop[0][l] ? pop[0][l] + (size_t)(cur == 0 ? shift : 0) * pplane : nullptr;
   }
   double* next_base(int l) const {
     if (!inplace) return pop[cur ^ 1][l];
-    return pop[0][l] ? pop[0][l] + (size_t)(cur == 0 ? 0 : shift) * plane : nullptr;
+    return pop[0][l] ? pop[0][l] + (size_t)(cur == 0 ? 0 : shift) * pplane : nullptr;
   }
-  long long dstride() const { return (long long)(nzl + 2 + shift) * (long long)plane; }
   bool rhs_ready = false;      // work[] holds the Poisson rhs of the current c, cn (written by the collide)
   bool streamed_state = true;  // true: pop[cur] holds X1 (post-stream, e.g. fresh equilibrium);
                                // false: pop[cur] holds post-collision populations (pull next)
@@ -151,7 +158,7 @@ struct Ctx {
   double* halo[4] = {};        // send-down, send-up, recv-from-below, recv-from-above
   size_t halo_doubles = 0;
   double* phi_halo[4] = {};
-  double* stage[MAXL] = {};    // in-place slabs: first/last plane of the new state, [27][2][plane]
+  double* stage[MAXL] = {};    // in-place slabs: first/last plane of the new state, 2 tiled planes
   // distributed tridiagonal (slab contexts)
   int slab_row_a = 0, slab_m = 0;  // first unknown row (local plane) and number of unknown rows
   double* slab_u = nullptr;        // u = A^-1 e_1, [slab_m][modes]

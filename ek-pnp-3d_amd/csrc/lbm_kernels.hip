@@ -11,9 +11,10 @@
 // Mapping to CDNA4: a workgroup is NL wave64s over the same 64 consecutive x nodes; wave l
 // owns lattice l (f, h, hn, temp), so each lane holds 27 FP64 populations (54 VGPRs) instead
 // of 108.  The waves exchange their seven moments through 3.5 KB of LDS, then every wave
-// collides its own lattice.  All 27 loads and 27 stores of a wave are 512-byte contiguous row
-// segments (x is the fastest index, LBM.cu:27-30); row bases are wave-uniform (SGPR) and only
-// the three x offsets live in VGPRs.
+// collides its own lattice.  Populations are tiled [zg][y][x/64][27][64] (ekpnp_internal.h): the 27
+// stores of a wave fill one contiguous 13.8 KB tile, the 27 loads are 512-byte segments of the
+// tiles of the 9 neighbour rows; row bases are wave-uniform (SGPR), the direction is an immediate
+// offset and only the three x offsets live in VGPRs.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(
   const bool act = x < a.nx;
   const int xc = act ? x : a.nx - 1;
   // source x for c_x = -1, 0, +1 (pull: x - c_x, periodic, LBM.cu:1970-1975)
-  const unsigned xs[3] = {(unsigned)(xc + 1 == a.nx ? 0 : xc + 1), (unsigned)xc, (unsigned)(xc == 0 ? a.nx - 1 : xc - 1)};
+  const unsigned xo[3] = {(unsigned)pop_xoff(xc + 1 == a.nx ? 0 : xc + 1), (unsigned)pop_xoff(xc), (unsigned)pop_xoff(xc == 0 ? a.nx - 1 : xc - 1)};
   const int ys[3] = {y + 1 == a.ny ? 0 : y + 1, y, y == 0 ? a.ny - 1 : y - 1};
 
   const double* __restrict__ src = a.A[lat];
@@ -178,8 +179,8 @@ __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(
   static_for<0, Q, 1>([&](auto ic) {
     constexpr int d = decltype(ic)::value;
     constexpr int cx = PULL ? ex_of(d) : 0, cy = PULL ? ey_of(d) : 0, cz = PULL ? ez_of(d) : 0;
-    const double* rowp = src + (long long)d * a.dstride + ((long long)(zg - cz) * a.ny + ys[cy + 1]) * (long long)a.nx;
-    f[d] = rowp[xs[cx + 1]];
+    const double* rowp = src + ((long long)(zg - cz) * a.ny + ys[cy + 1]) * a.rowstride + d * 64;
+    f[d] = rowp[xo[cx + 1]];
   });
 
   if constexpr (NL > 1) {
@@ -219,16 +220,15 @@ __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(
   const double uy = rhoinv * (jy * a.cflinv + F.y * hdt);
   const double uz = rhoinv * (jz * a.cflinv + F.z * hdt);
 
-  double* __restrict__ dst = a.B[lat];
-  const long long orow = ((long long)zg * a.ny + y) * (long long)a.nx + xc;
+  double* __restrict__ dst = a.B[lat] + ((long long)zg * a.ny + y) * a.rowstride + xo[1];
   auto store = [&](auto ic, double v) {
     constexpr int d = decltype(ic)::value;
     // non-temporal: the populations written here are not read again before the next step
     // (+1 % on cfg3, profiles/r01_sweep_libs.log); EKPNP_PLAIN_STORES builds the A/B partner
 #ifdef EKPNP_PLAIN_STORES
-    if (act) dst[(long long)d * a.dstrideB + orow] = v;
+    if (act) dst[d * 64] = v;
 #else
-    if (act) __builtin_nontemporal_store(v, dst + (long long)d * a.dstrideB + orow);
+    if (act) __builtin_nontemporal_store(v, dst + d * 64);
 #endif
   };
   if (lat == 0) {
@@ -271,7 +271,7 @@ __device__ __forceinline__ void gather(const KArgs& a, const double* __restrict_
       // plane directly instead of a ghost-plane copy of it
       if (a.zwrap) zs = zs == 0 ? a.nzl : (zs == a.nzl + 1 ? 1 : zs);
     }
-    f[d] = src[(long long)d * a.dstride + ((long long)zs * a.ny + ys[cy + 1]) * (long long)a.nx + xs[cx + 1]];
+    f[d] = src[((long long)zs * a.ny + ys[cy + 1]) * a.rowstride + d * 64 + pop_xoff(xs[cx + 1])];
   });
 }
 
@@ -284,10 +284,10 @@ __device__ __forceinline__ void wall_scalar_pops(const KArgs& a, int lat, const 
   if constexpr (!PULL) {
     gather<false>(a, src, x, y, zg, f);
   } else {
-    const long long o = ((long long)zg * a.ny + y) * (long long)a.nx + x;
+    const long long o = ((long long)zg * a.ny + y) * a.rowstride + pop_xoff(x);
     static_for<0, Q, 1>([&](auto ic) {
       constexpr int d = decltype(ic)::value;
-      const double v = src[(long long)opp_of(d) * a.dstride + o];
+      const double v = src[opp_of(d) * 64 + o];
       f[d] = (lat == 3) ? (-v + 2.0 * TH_wall * w_of(d)) : v;
     });
   }
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int fi
   const int zg = zl + 1;
   const double TH_wall = top ? 0.0 : a.TH;  // LBM.cu:2226-2229 vs 2357-2412
   const long long sidx = ((long long)zl * a.ny + y) * (long long)a.nx + x;
-  const long long orow = ((long long)zg * a.ny + y) * (long long)a.nx + x;
+  const long long orow = ((long long)zg * a.ny + y) * a.rowstride + pop_xoff(x);
 
   double f[Q];
   gather<PULL>(a, a.A[0], x, y, zg, f);
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int fi
         constexpr int sgn = (ex_of(d) > 0 || d == 3) ? 1 : (ex_of(d) < 0 ? -1 : 0);  // LBM.cu:1902-1927
         if constexpr (sgn != 0) v = v + sgn * (a.uw_multi * w_of(d));
       }
-      dst[(long long)d * a.dstrideB + orow] = v;
+      dst[d * 64 + orow] = v;
     });
   }
   // ions and temperature collide on the wall like anywhere else (their post-collision values
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int fi
       double* __restrict__ dst = a.B[lat];
       auto store = [&](auto ic, double v) {
         constexpr int d = decltype(ic)::value;
-        dst[(long long)d * a.dstrideB + orow] = v;
+        dst[d * 64 + orow] = v;
       };
       const double k = a.mob[lat];
       collide_scalar(a, g, ms[lat - 1], ux + k * Ex, uy + k * Ey, uz + k * Ez, a.wp[lat], a.wm[lat], store);
@@ -415,71 +415,77 @@ __global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int fi
 // z-periodic ghost loop of gpu_stream (LBM.cu:1972,1975) for a single slab, and the slab halo
 // pack/unpack.  Buffers: [lattice][9 dirs][ny][nx].
 
-__global__ void k_ghost_wrap(double* p0, double* p1, double* p2, double* p3, int nl, long long plane, long long dstride, int nzl) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= plane) return;
-  const int k = blockIdx.y;
+// tiled offset of node (x, y) of plane zg for direction d = 0 (add d*64)
+struct PopGeom {
+  int nx, ny, nzl;
+  long long rowstride, pplane;
+  __device__ long long at(int zg, int y, int x) const { return (long long)zg * pplane + (long long)y * rowstride + pop_xoff(x); }
+};
+
+__global__ void k_ghost_wrap(double* p0, double* p1, double* p2, double* p3, int nl, PopGeom g) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+  if (x >= g.nx) return;
   double* pp[MAXL] = {p0, p1, p2, p3};
+  const int du = up_dir(k) * 64, dd = dn_dir(k) * 64;
   for (int l = 0; l < nl; ++l) {
     double* p = pp[l];
-    const int du = up_dir(k), dd = dn_dir(k);
-    p[(long long)du * dstride + i] = p[(long long)du * dstride + (long long)nzl * plane + i];              // ghost below <- top plane
-    p[(long long)dd * dstride + (long long)(nzl + 1) * plane + i] = p[(long long)dd * dstride + plane + i];  // ghost above <- bottom plane
+    p[g.at(0, y, x) + du] = p[g.at(g.nzl, y, x) + du];      // ghost below <- top plane
+    p[g.at(g.nzl + 1, y, x) + dd] = p[g.at(1, y, x) + dd];  // ghost above <- bottom plane
   }
 }
 
-__global__ void k_halo_pack(const double* p0, const double* p1, const double* p2, const double* p3, int nl, long long plane,
-                            long long dstride, int nzl, double* send_dn, double* send_up) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= plane) return;
-  const int k = blockIdx.y;
+__global__ void k_halo_pack(const double* p0, const double* p1, const double* p2, const double* p3, int nl, PopGeom g, double* send_dn,
+                            double* send_up) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+  if (x >= g.nx) return;
+  const long long plane = (long long)g.nx * g.ny, i = (long long)y * g.nx + x;
   const double* pp[MAXL] = {p0, p1, p2, p3};
   for (int l = 0; l < nl; ++l) {
     const double* p = pp[l];
-    send_up[((long long)l * 9 + k) * plane + i] = p[(long long)up_dir(k) * dstride + (long long)nzl * plane + i];
-    send_dn[((long long)l * 9 + k) * plane + i] = p[(long long)dn_dir(k) * dstride + plane + i];
+    send_up[((long long)l * 9 + k) * plane + i] = p[g.at(g.nzl, y, x) + up_dir(k) * 64];
+    send_dn[((long long)l * 9 + k) * plane + i] = p[g.at(1, y, x) + dn_dir(k) * 64];
   }
 }
 
-// In-place slabs: the slab's first and last plane are collided into a 2-plane staging buffer
-// [27][2][ny][nx] per lattice (they must exist before the ordered sweep of the planes in between
-// may start, so that the halo exchange can overlap it); the halo is packed from there and the
-// two planes are copied into the lattice after the sweep.
-__global__ void k_halo_pack_stage(const double* s0, const double* s1, const double* s2, const double* s3, int nl, long long plane,
+// In-place slabs: the slab's first and last plane are collided into a 2-plane staging buffer (two
+// tiled planes per lattice; they must exist before the ordered sweep of the planes in between may
+// start, so that the halo exchange can overlap it); the halo is packed from there and the two
+// planes are copied into the lattice after the sweep.
+__global__ void k_halo_pack_stage(const double* s0, const double* s1, const double* s2, const double* s3, int nl, PopGeom g,
                                   double* send_dn, double* send_up) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= plane) return;
-  const int k = blockIdx.y;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+  if (x >= g.nx) return;
+  const long long plane = (long long)g.nx * g.ny, i = (long long)y * g.nx + x;
   const double* ss[MAXL] = {s0, s1, s2, s3};
   for (int l = 0; l < nl; ++l) {
-    send_up[((long long)l * 9 + k) * plane + i] = ss[l][((long long)up_dir(k) * 2 + 1) * plane + i];  // last plane
-    send_dn[((long long)l * 9 + k) * plane + i] = ss[l][((long long)dn_dir(k) * 2 + 0) * plane + i];  // first plane
+    send_up[((long long)l * 9 + k) * plane + i] = ss[l][g.at(1, y, x) + up_dir(k) * 64];  // last plane
+    send_dn[((long long)l * 9 + k) * plane + i] = ss[l][g.at(0, y, x) + dn_dir(k) * 64];  // first plane
   }
 }
 
+// staging planes 0 / 1 -> planes zg = 1 / zg = nzl (whole tiled planes, pad lanes included)
 __global__ void k_unstage(double* p0, double* p1, double* p2, double* p3, const double* s0, const double* s1, const double* s2,
-                          const double* s3, int nl, long long plane, long long dstride, int nzl) {
+                          const double* s3, int nl, long long pplane, int nzl) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= plane) return;
-  const int d = blockIdx.y;
+  if (i >= pplane) return;
   double* pp[MAXL] = {p0, p1, p2, p3};
   const double* ss[MAXL] = {s0, s1, s2, s3};
   for (int l = 0; l < nl; ++l) {
-    pp[l][(long long)d * dstride + plane + i] = ss[l][((long long)d * 2 + 0) * plane + i];
-    pp[l][(long long)d * dstride + (long long)nzl * plane + i] = ss[l][((long long)d * 2 + 1) * plane + i];
+    pp[l][pplane + i] = ss[l][i];
+    pp[l][(long long)nzl * pplane + i] = ss[l][pplane + i];
   }
 }
 
-__global__ void k_halo_unpack(double* p0, double* p1, double* p2, double* p3, int nl, long long plane, long long dstride, int nzl,
-                              const double* recv_lo, const double* recv_hi) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= plane) return;
-  const int k = blockIdx.y;
+__global__ void k_halo_unpack(double* p0, double* p1, double* p2, double* p3, int nl, PopGeom g, const double* recv_lo,
+                              const double* recv_hi) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+  if (x >= g.nx) return;
+  const long long plane = (long long)g.nx * g.ny, i = (long long)y * g.nx + x;
   double* pp[MAXL] = {p0, p1, p2, p3};
   for (int l = 0; l < nl; ++l) {
     double* p = pp[l];
-    p[(long long)up_dir(k) * dstride + i] = recv_lo[((long long)l * 9 + k) * plane + i];
-    p[(long long)dn_dir(k) * dstride + (long long)(nzl + 1) * plane + i] = recv_hi[((long long)l * 9 + k) * plane + i];
+    p[g.at(0, y, x) + up_dir(k) * 64] = recv_lo[((long long)l * 9 + k) * plane + i];
+    p[g.at(g.nzl + 1, y, x) + dn_dir(k) * 64] = recv_hi[((long long)l * 9 + k) * plane + i];
   }
 }
 
@@ -527,7 +533,8 @@ __global__ void k_init_equilibrium(KArgs a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = (long long)a.nzl * a.plane;
   if (i >= n) return;
-  const long long o = i + a.plane;  // ghost plane below
+  const int x = (int)(i % a.nx), y = (int)((i / a.nx) % a.ny), zg = (int)(i / a.plane) + 1;  // ghost plane below
+  const long long o = ((long long)zg * a.ny + y) * a.rowstride + pop_xoff(x);
   const double rho = a.fld[EKPNP_RHO][i], ux = a.fld[EKPNP_UX][i], uy = a.fld[EKPNP_UY][i], uz = a.fld[EKPNP_UZ][i];
   const double Ex = a.fld[EKPNP_EX][i], Ey = a.fld[EKPNP_EY][i], Ez = a.fld[EKPNP_EZ][i];
   double eq[Q];
@@ -538,7 +545,7 @@ __global__ void k_init_equilibrium(KArgs a) {
     equilibrium(a, m, ux + k * Ex, uy + k * Ey, uz + k * Ez, eq);
     double* dst = a.B[lat];
 #pragma unroll
-    for (int d = 0; d < Q; ++d) dst[(long long)d * a.dstrideB + o] = eq[d];
+    for (int d = 0; d < Q; ++d) dst[d * 64 + o] = eq[d];
   });
 }
 
@@ -624,37 +631,36 @@ void launch_collide_walls(Ctx& c, const KArgs& a, hipStream_t stream, bool want_
   }
 }
 
+static PopGeom pop_geom(const Ctx& c) { return PopGeom{c.p.nx, c.p.ny, c.nzl, (long long)c.rowstride, (long long)c.pplane}; }
+static dim3 halo_grid(const Ctx& c) { return dim3((unsigned)((c.p.nx + 255) / 256), (unsigned)c.p.ny, 9); }
+
 void launch_ghost_wrap(Ctx& c) {
   double* p[MAXL] = {c.cur_base(0), c.cur_base(1), c.cur_base(2), c.cur_base(3)};
-  dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
-  hipLaunchKernelGGL(k_ghost_wrap, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane, c.dstride(), c.nzl);
+  hipLaunchKernelGGL(k_ghost_wrap, halo_grid(c), dim3(256), 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, pop_geom(c));
 }
 
 void launch_halo_pack(Ctx& c, int buffer) {
   double** p = c.pop[buffer];
-  dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
-  hipLaunchKernelGGL(k_halo_pack, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane,
-                     (long long)(c.nzl + 2) * (long long)c.plane, c.nzl, c.halo[0], c.halo[1]);
+  hipLaunchKernelGGL(k_halo_pack, halo_grid(c), dim3(256), 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, pop_geom(c), c.halo[0],
+                     c.halo[1]);
 }
 
 void launch_halo_unpack(Ctx& c) {
   double* p[MAXL] = {c.cur_base(0), c.cur_base(1), c.cur_base(2), c.cur_base(3)};
-  dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
-  hipLaunchKernelGGL(k_halo_unpack, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, (long long)c.plane, c.dstride(), c.nzl,
-                     c.halo[2], c.halo[3]);
+  hipLaunchKernelGGL(k_halo_unpack, halo_grid(c), dim3(256), 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, pop_geom(c), c.halo[2],
+                     c.halo[3]);
 }
 
 void launch_halo_pack_stage(Ctx& c) {
-  dim3 g((unsigned)((c.plane + 255) / 256), 9), b(256);
-  hipLaunchKernelGGL(k_halo_pack_stage, g, b, 0, c.stream, c.stage[0], c.stage[1], c.stage[2], c.stage[3], c.p.n_lattices,
-                     (long long)c.plane, c.halo[0], c.halo[1]);
+  hipLaunchKernelGGL(k_halo_pack_stage, halo_grid(c), dim3(256), 0, c.stream, c.stage[0], c.stage[1], c.stage[2], c.stage[3],
+                     c.p.n_lattices, pop_geom(c), c.halo[0], c.halo[1]);
 }
 
 void launch_unstage(Ctx& c) {
   double* p[MAXL] = {c.cur_base(0), c.cur_base(1), c.cur_base(2), c.cur_base(3)};
-  dim3 g((unsigned)((c.plane + 255) / 256), Q), b(256);
-  hipLaunchKernelGGL(k_unstage, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.stage[0], c.stage[1], c.stage[2], c.stage[3],
-                     c.p.n_lattices, (long long)c.plane, c.dstride(), c.nzl);
+  dim3 g((unsigned)((c.pplane + 255) / 256)), b(256);
+  hipLaunchKernelGGL(k_unstage, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.stage[0], c.stage[1], c.stage[2], c.stage[3], c.p.n_lattices,
+                     (long long)c.pplane, c.nzl);
 }
 
 }  // namespace ekpnp

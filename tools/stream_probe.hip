@@ -186,6 +186,55 @@ __global__ void klbm_tiled(const double* __restrict__ a, double* __restrict__ b,
     if (d < nd) orow[d * 64 + ox[1]] = acc[d];
 }
 
+
+// AoSoA layout [z][y][x/64][27][64] per lattice (lattices on separate arrays, a + l*lstride), with the
+// bulk kernel's XCD row-run mapping: a workgroup writes 4 x 13.8 KB contiguous chunks; pulls come from 9
+// neighbour rows' chunks (+ one element of the adjacent x block for the 18 directions with c_x != 0).
+// merged != 0: lattices inside the tile, [z][y][x/64][4][27][64] (one 55 KB chunk per workgroup).
+__global__ void klbm_aosoa(const double* __restrict__ a, double* __restrict__ b, int nx, int ny, int nz, long long lstride, int nxb, int rchunk, int merged, int mode) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int r = slot / nxb, xb = slot - r * nxb;
+  const int row = ((r / rchunk) * 8 + xcd) * rchunk + r % rchunk;
+  if (row >= ny * nz) return;
+  const int lat = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int y = row % ny, z = row / ny + 1;
+  const long long tile = merged ? 4LL * 27 * 64 : 27LL * 64;
+  const long long rowstride = (long long)nxb * tile;
+  const double* aa = merged ? a + lat * 27 * 64 : a + lat * lstride;
+  double* bb = merged ? b + lat * 27 * 64 : b + lat * lstride;
+  const int ym = y == 0 ? ny - 1 : y - 1, yp = y + 1 == ny ? 0 : y + 1;
+  const int xbm = xb == 0 ? nxb - 1 : xb - 1, xbp = xb + 1 == nxb ? 0 : xb + 1;
+  // element offsets inside a row for c_x = -1 (pull from x+1), 0, +1 (pull from x-1)
+  const long long ox[3] = {lane == 63 ? xbp * tile : xb * tile + lane + 1, xb * tile + lane, lane == 0 ? xbm * tile + 63 : xb * tile + lane - 1};
+  double acc[27];
+#pragma unroll
+  for (int d = 0; d < 27; ++d) {
+    // mode bit 2: a direction numbering in which the three c_x of one (c_y, c_z) are NOT neighbours
+    const int dd = (mode & 4) ? (d * 10) % 27 : d;
+    int cx = (dd % 3) - 1, cy = ((dd / 3) % 3) - 1, cz = (dd / 9) - 1;
+    if (mode & 1) cx = 0;
+    if (mode & 2) cy = cz = 0;
+    const int ys = cy < 0 ? yp : cy > 0 ? ym : y;
+    acc[d] = aa[((long long)(z - cz) * ny + ys) * rowstride + d * 64 + ox[cx + 1]];
+  }
+  double* orow = bb + ((long long)z * ny + y) * rowstride + ox[1];
+#pragma unroll
+  for (int d = 0; d < 27; ++d) orow[d * 64] = acc[d];
+}
+
+__global__ void k_read_only(const double* __restrict__ a, double* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double s = 0;
+  for (; i < n; i += stride) s += a[i];
+  if (s == 12345.678) out[0] = s;
+}
+__global__ void k_write_only(double* __restrict__ b, size_t n, double v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = v;
+}
+
 template <class F>
 static void timeit(const char* name, double bytes, F f) {
   hipEvent_t e0, e1;
@@ -216,6 +265,8 @@ int main() {
   timeit("copy 16B/lane aligned", bytes, [&] { hipLaunchKernelGGL(k16, g16, blk, 0, 0, a, b, n, 0); });
   timeit("copy 16B/lane 2x8B shifted loads", bytes, [&] { hipLaunchKernelGGL(k16, g16, blk, 0, 0, a, b, n, 1); });
   timeit("copy 16B/lane unaligned x4 load", bytes, [&] { hipLaunchKernelGGL(k16u, g16, blk, 0, 0, a, b, n, 1); });
+  timeit("read only (grid-stride sum)", 8.0 * n, [&] { hipLaunchKernelGGL(k_read_only, dim3(256 * 32), blk, 0, 0, a, b, n); });
+  timeit("write only (fill)", 8.0 * n, [&] { hipLaunchKernelGGL(k_write_only, g8, blk, 0, 0, b, n, 1.0); });
   CK(hipFree(a)); CK(hipFree(b));
   // LBM-shaped: 512x512x(130) planes, 27 streams
   const int nx = 512, ny = 512, nz = 130;
@@ -253,25 +304,22 @@ int main() {
       snprintf(nm, sizeof nm, "lbm-shape 4 lattices x 27, rchunk %d%s", rc, nt ? " nt" : "");
       timeit(nm, lb4, [&] { hipLaunchKernelGGL(klbm_chunk, dim3((unsigned)(8 * per * nxb)), dim3(256), 0, 0, a, b, nx, ny, nzc, ds, ls, nxb, rc, nt); });
     }
-  }
-  {
-    const int nzc = 128;
-    const long long ds = (long long)nx * ny * (nzc + 2);
-    const double lb4 = 16.0 * 27 * 4 * nx * ny * (double)nzc;
-    const int nxb = nx / 64;
-    for (int rc : {8}) for (int nt : {0}) {
+    for (int merged : {0, 1}) for (int rc : {1, 8, 64}) {
       const long long nrows = (long long)ny * nzc;
       const long long per = (nrows + 8LL * rc - 1) / (8LL * rc) * rc;
       char nm[80];
-      snprintf(nm, sizeof nm, "lbm-shape INTERLEAVED [d][z][y][x][4], rchunk %d%s", rc, nt ? " nt" : "");
-      timeit(nm, lb4, [&] { hipLaunchKernelGGL(klbm_inter, dim3((unsigned)(8 * per * nxb)), dim3(256), 0, 0, (const quad*)a, (quad*)b, nx, ny, nzc, ds, nxb, rc, nt); });
+      snprintf(nm, sizeof nm, "lbm-shape AoSoA %s, rchunk %d", merged ? "[z][y][xb][4][27][64]" : "4 x [z][y][xb][27][64]", rc);
+      timeit(nm, lb4, [&] { hipLaunchKernelGGL(klbm_aosoa, dim3((unsigned)(8 * per * nxb)), dim3(256), 0, 0, a, b, nx, ny, nzc, ls, nxb, rc, merged, 0); });
     }
-  }
-  for (int bx : {64}) {
-    dim3 g(nx / bx, ny, nz), bb(bx);
-    char nm[64];
-    snprintf(nm, sizeof nm, "lbm-shape TILED [z][y][xt][27][64], block %d", bx);
-    if (false) timeit(nm, lb, [&] { hipLaunchKernelGGL(klbm_tiled, g, bb, 0, 0, a, b, nx, ny, nz, 27); });
+    for (int merged : {0, 1}) for (int mode : {1, 2, 3, 4}) {
+      const int rc = 64;
+      const long long nrows = (long long)ny * nzc;
+      const long long per = (nrows + 8LL * rc - 1) / (8LL * rc) * rc;
+      char nm[96];
+      snprintf(nm, sizeof nm, "AoSoA merged=%d rchunk 64 %s%s%s", merged, mode & 1 ? "no-x-shift " : "", mode & 2 ? "no-yz-offset " : "", mode & 4 ? "scattered-dirs" : "");
+      timeit(nm, lb4, [&] { hipLaunchKernelGGL(klbm_aosoa, dim3((unsigned)(8 * per * nxb)), dim3(256), 0, 0, a, b, nx, ny, nzc, ls, nxb, rc, merged, mode); });
+    }
+    CK(hipFree(a)); CK(hipFree(b));
   }
   return 0;
 }

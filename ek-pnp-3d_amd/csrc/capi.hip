@@ -129,6 +129,7 @@ PArgs Ctx::pargs() const {
   for (int i = 0; i < EKPNP_NFIELDS; ++i) a.fld[i] = fld[i];
   a.work = work; a.spec = spec; a.cprime = cprime;
   a.phi_lo = phi_halo[2]; a.phi_hi = phi_halo[3];
+  a.vwall = vwall;
   a.nx = p.nx; a.ny = p.ny; a.nz = p.nz; a.nxh = nxh; a.nzl = nzl; a.z0 = z0;
   a.plane = (long long)plane;
   a.F = p.convertCtoCharge; a.eps = p.eps; a.voltage = p.voltage; a.voltage2 = p.voltage2;
@@ -227,6 +228,11 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   const size_t nmodes = (size_t)p->ny * c.nxh;
   const size_t cprime_rows = !slab ? (size_t)p->nz : (size_t)c.nzl + 2;
   if ((rc = dev_alloc(c, (void**)&c.cprime, cprime_rows * nmodes * sizeof(double)))) return bail(rc);
+  {
+    const double vw[2] = {p->voltage, p->voltage2};
+    if ((rc = dev_alloc(c, (void**)&c.vwall, sizeof(vw)))) return bail(rc);
+    if (hipMemcpy(c.vwall, vw, sizeof(vw), hipMemcpyHostToDevice) != hipSuccess) { c.err = "hipMemcpy failed"; return bail(EKPNP_ERR_HIP); }
+  }
   c.halo_doubles = (size_t)p->n_lattices * 9 * c.plane;
   if (slab) {
     if (nranks > 16) { c.err = "at most 16 z slabs"; return bail(EKPNP_ERR_INVALID); }
@@ -292,6 +298,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (c.edge_all) (void)hipFree(c.edge_all);
   if (c.phi_old) (void)hipFree(c.phi_old);
   if (c.diag) (void)hipFree(c.diag);
+  if (c.vwall) (void)hipFree(c.vwall);
   for (int k = 0; k < 4; ++k) {
     if (c.halo[k]) (void)hipFree(c.halo[k]);
     if (c.phi_halo[k]) (void)hipFree(c.phi_halo[k]);

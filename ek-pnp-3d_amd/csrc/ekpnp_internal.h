@@ -85,6 +85,7 @@ struct PArgs {
   const double* cprime;        // Thomas table [nz][ny][nxh] (global z index)
   const double* phi_lo;        // phi plane below / above the slab (slab mode), may be null
   const double* phi_hi;
+  const double* vwall;         // {voltage, voltage2} in device memory
   int nx, ny, nz, nxh, nzl, z0;
   long long plane;
   double F, eps, voltage, voltage2, inv_dz2, dx, dy, dz, inv_nxny;
@@ -167,6 +168,7 @@ struct Ctx {
   double* edge_all = nullptr;      // [nranks][4][modes]
   double* phi_old = nullptr;       // PB relaxation state (ekpnp_pbe_begin/end)
   double* diag = nullptr;          // reduction scratch (DIAG_SCRATCH doubles)
+  double* vwall = nullptr;         // {voltage, voltage2}
   int collide_phase = 0;           // 0 idle, 1 boundary planes done
   // hipGraph of two consecutive steps (A->B, B->A) for launch-bound lattices
   hipGraphExec_t graph2 = nullptr;

@@ -145,15 +145,46 @@ __device__ __forceinline__ double phi_at(const PArgs& a, int x, int y, int z /*g
 // planes marched per thread: 16 on large lattices (no measurable difference between 1 and 64
 // there, profiles/r01_sweep_phi_zchunk.log), 1 on small ones where the serial chain of a column
 // would be the whole run time of the kernel
-constexpr int PHI_ZCHUNK_LARGE = 16;
+#ifndef EKPNP_PHI_ZCHUNK
+#define EKPNP_PHI_ZCHUNK 16  // tuning knob
+#endif
+constexpr int PHI_ZCHUNK_LARGE = EKPNP_PHI_ZCHUNK;
 
 // One thread marches up a column of PHI_ZCHUNK planes with phi(z-1), phi(z), phi(z+1) in
 // registers: every phi value is read once for the three z uses (the x+-1 / y+-1 neighbours come
 // from the same or the adjacent row, i.e. from cache).
 //
+// z is uniform over the workgroup, so every case distinction (wall plane, slab halo) is a scalar
+// select of a pointer / scale / value - no branch surrounds a load - and the five loads of plane
+// z+1 are issued before the four stores of plane z (a first version with phi_at() per operand
+// compiled to load - wait - store chains: 1.71 ms on 512^3 against 0.9 ms at copy speed).
+//
 // XCD-aware placement as in k_collide_bulk: the (y, z-chunk) rows are dealt to the 8 XCDs in
 // runs of 64 consecutive y, so the y+-1 neighbour rows are found in the XCD's own L2 (with rows
 // dealt one by one every L2 fetched all three rows: 4.1 GB fetched for 1.07 GB of phi).
+struct PhiColumn {
+  const double* __restrict__ work;
+  const double* __restrict__ lo;
+  const double* __restrict__ hi;
+  const double* __restrict__ vwall;  // {voltage, voltage2} in device memory: the wall case is a pointer select too
+  long long plane, oc;
+  int z0, nzl, nz;
+  double inv;
+  // phi(x, y, z) for z0-1 <= z <= z0+nzl (phi_at() without branches: one unconditional load)
+  __device__ __forceinline__ double center(int z) const {
+    const int zl = z - z0;
+    const bool wall_lo = z <= 0, wall_hi = z >= nz - 1;
+    const bool own = !wall_lo && !wall_hi && zl >= 0 && zl < nzl;
+    const int zc = zl < 0 ? 0 : (zl >= nzl ? nzl - 1 : zl);
+    const double* p = work + (long long)zc * plane + oc;
+    p = zl < 0 ? lo + oc : p;
+    p = zl >= nzl ? hi + oc : p;
+    p = wall_lo ? vwall : p;
+    p = wall_hi ? vwall + 1 : p;
+    return *p * (own ? inv : 1.0);
+  }
+};
+
 template <int PHI_ZCHUNK>
 __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, const int nrows) {
   constexpr int RCHUNK = 64;
@@ -169,24 +200,56 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
   const int zl1 = min(zl0 + PHI_ZCHUNK, a.nzl);
   const int xp1 = x + 1 == a.nx ? 0 : x + 1, xm1 = x == 0 ? a.nx - 1 : x - 1;
   const int yp1 = y + 1 == a.ny ? 0 : y + 1, ym1 = y == 0 ? a.ny - 1 : y - 1;
-  double pm = phi_at(a, x, y, a.z0 + zl0 - 1);
-  double p0 = phi_at(a, x, y, a.z0 + zl0);
+  const long long oc = (long long)y * a.nx + x;
+  const long long oxm = (long long)y * a.nx + xm1, oxp = (long long)y * a.nx + xp1;
+  const long long oym = (long long)ym1 * a.nx + x, oyp = (long long)yp1 * a.nx + x;
+  const PhiColumn col{a.work, a.phi_lo, a.phi_hi, a.vwall, a.plane, oc, a.z0, a.nzl, a.nz, a.inv_nxny};
+  const double* __restrict__ w = a.work;
+  double* __restrict__ o_phi = a.fld[EKPNP_PHI];
+  double* __restrict__ o_ex = a.fld[EKPNP_EX];
+  double* __restrict__ o_ey = a.fld[EKPNP_EY];
+  double* __restrict__ o_ez = a.fld[EKPNP_EZ];
+
+  double pm = col.center(a.z0 + zl0 - 1);
+  double p0 = col.center(a.z0 + zl0);
+  // operands of plane zl0
+  const double* wz = w + (long long)zl0 * a.plane;
+  double nxm = wz[oxm], nxp = wz[oxp], nym = wz[oym], nyp = wz[oyp];
+  double pp = col.center(a.z0 + zl0 + 1);
+#pragma unroll 4
   for (int zl = zl0; zl < zl1; ++zl) {
     const int z = a.z0 + zl;
-    const double pp = phi_at(a, x, y, z + 1);
-    const long long i = ((long long)zl * a.ny + y) * a.nx + x;
-    a.fld[EKPNP_PHI][i] = p0;
+    // next plane's operands first (clamped to the chunk: the last iteration re-reads its own plane)
+    const int zn = zl + 1 < zl1 ? zl + 1 : zl;
+    const double* wn = w + (long long)zn * a.plane;
+    const double n_xm = wn[oxm], n_xp = wn[oxp], n_ym = wn[oym], n_yp = wn[oyp];
+    const double n_pp = col.center(a.z0 + zn + 1);
+
+    const bool wall = z == 0 || z == a.nz - 1;
+    const double vw = z == 0 ? a.voltage : a.voltage2;
+    const double exm = wall ? vw : nxm * a.inv_nxny, exp_ = wall ? vw : nxp * a.inv_nxny;
+    const double eym = wall ? vw : nym * a.inv_nxny, eyp = wall ? vw : nyp * a.inv_nxny;
+    const long long i = (long long)zl * a.plane + oc;
+#ifdef EKPNP_PHI_NT
+#define PHI_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define PHI_ST(ptr, v) (*(ptr) = (v))
+#endif
+    PHI_ST(o_phi + i, p0);
     // the reference's expression 0.5*(a - b)/d (poisson.cu:53-55), kept so that E is the same
     // bits as a central difference of the returned phi
-    a.fld[EKPNP_EX][i] = 0.5 * (phi_at(a, xm1, y, z) - phi_at(a, xp1, y, z)) / a.dx;
-    a.fld[EKPNP_EY][i] = 0.5 * (phi_at(a, x, ym1, z) - phi_at(a, x, yp1, z)) / a.dy;
-    double ez;
-    if (z == 0) ez = 0.5 * (p0 - phi_at(a, x, y, 2)) / a.dz;                    // gpu_bc: Ez(0) <- Ez(1)
-    else if (z == a.nz - 1) ez = 0.5 * (phi_at(a, x, y, a.nz - 3) - p0) / a.dz;  // gpu_bc: Ez(NZ-1) <- Ez(NZ-2)
-    else ez = 0.5 * (pm - pp) / a.dz;
-    a.fld[EKPNP_EZ][i] = ez;
+    PHI_ST(o_ex + i, 0.5 * (exm - exp_) / a.dx);
+    PHI_ST(o_ey + i, 0.5 * (eym - eyp) / a.dy);
+    const double ez = 0.5 * (pm - pp) / a.dz;
+    // gpu_bc (poisson.cu:57-69): Ez(0) <- Ez(1), Ez(NZ-1) <- Ez(NZ-2); planes 0,1 and NZ-2,NZ-1 always
+    // belong to the same slab, so the interior plane's thread writes its wall neighbour too
+    if (!wall) PHI_ST(o_ez + i, ez);
+    if (z == 1) PHI_ST(o_ez + i - a.plane, ez);
+    if (z == a.nz - 2) PHI_ST(o_ez + i + a.plane, ez);
     pm = p0;
     p0 = pp;
+    pp = n_pp;
+    nxm = n_xm; nxp = n_xp; nym = n_ym; nyp = n_yp;
   }
 }
 
@@ -393,7 +456,10 @@ void launch_tridiag(Ctx& c) {
 
 void launch_phi_efield(Ctx& c) {
   PArgs a = c.pargs();
-  const int bx = c.p.nx >= 256 ? 256 : 64;
+#ifndef EKPNP_PHI_BX
+#define EKPNP_PHI_BX 256  // tuning knob
+#endif
+  const int bx = c.p.nx >= EKPNP_PHI_BX ? EKPNP_PHI_BX : 64;
   const int nxb = (c.p.nx + bx - 1) / bx;
   const bool small = c.nloc < (size_t)2 * 1024 * 1024;
   const int zchunk = small ? 1 : PHI_ZCHUNK_LARGE;

@@ -177,8 +177,15 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info()
     wname, (nx, ny, nz), nl, use_in_place = parse_workload(args.workload, free_b, args.in_place)
     dist = None
+    saved_stdout = None
     if world > 1 or args.force_slab:
         import torch.distributed as dist  # noqa: WPS440
+
+        # RCCL prints a version banner on the C-level stdout when its first communicator is made;
+        # stdout is for the ONE JSON line, so fd 1 points at stderr until that line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
 
         kw = {}
         if "RANK" not in os.environ:  # plain `python bench.py --force-slab`
@@ -319,6 +326,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             runner.close()
             out["cpu_baseline"] = cpu_baseline(nl)
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -145,10 +145,7 @@ __device__ __forceinline__ double phi_at(const PArgs& a, int x, int y, int z /*g
 // planes marched per thread: 16 on large lattices (no measurable difference between 1 and 64
 // there, profiles/r01_sweep_phi_zchunk.log), 1 on small ones where the serial chain of a column
 // would be the whole run time of the kernel
-#ifndef EKPNP_PHI_ZCHUNK
-#define EKPNP_PHI_ZCHUNK 16  // tuning knob
-#endif
-constexpr int PHI_ZCHUNK_LARGE = EKPNP_PHI_ZCHUNK;
+constexpr int PHI_ZCHUNK_LARGE = 16;
 
 // One thread marches up a column of PHI_ZCHUNK planes with phi(z-1), phi(z), phi(z+1) in
 // registers: every phi value is read once for the three z uses (the x+-1 / y+-1 neighbours come
@@ -230,22 +227,19 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
     const double exm = wall ? vw : nxm * a.inv_nxny, exp_ = wall ? vw : nxp * a.inv_nxny;
     const double eym = wall ? vw : nym * a.inv_nxny, eyp = wall ? vw : nyp * a.inv_nxny;
     const long long i = (long long)zl * a.plane + oc;
-#ifdef EKPNP_PHI_NT
-#define PHI_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
-#else
-#define PHI_ST(ptr, v) (*(ptr) = (v))
-#endif
-    PHI_ST(o_phi + i, p0);
+    // (plain stores: non-temporal ones, other chunk lengths and block widths measured the same,
+    // profiles/r01_sweep_phi_variants.log)
+    o_phi[i] = p0;
     // the reference's expression 0.5*(a - b)/d (poisson.cu:53-55), kept so that E is the same
     // bits as a central difference of the returned phi
-    PHI_ST(o_ex + i, 0.5 * (exm - exp_) / a.dx);
-    PHI_ST(o_ey + i, 0.5 * (eym - eyp) / a.dy);
+    o_ex[i] = 0.5 * (exm - exp_) / a.dx;
+    o_ey[i] = 0.5 * (eym - eyp) / a.dy;
     const double ez = 0.5 * (pm - pp) / a.dz;
     // gpu_bc (poisson.cu:57-69): Ez(0) <- Ez(1), Ez(NZ-1) <- Ez(NZ-2); planes 0,1 and NZ-2,NZ-1 always
     // belong to the same slab, so the interior plane's thread writes its wall neighbour too
-    if (!wall) PHI_ST(o_ez + i, ez);
-    if (z == 1) PHI_ST(o_ez + i - a.plane, ez);
-    if (z == a.nz - 2) PHI_ST(o_ez + i + a.plane, ez);
+    if (!wall) o_ez[i] = ez;
+    if (z == 1) o_ez[i - a.plane] = ez;
+    if (z == a.nz - 2) o_ez[i + a.plane] = ez;
     pm = p0;
     p0 = pp;
     pp = n_pp;
@@ -456,10 +450,7 @@ void launch_tridiag(Ctx& c) {
 
 void launch_phi_efield(Ctx& c) {
   PArgs a = c.pargs();
-#ifndef EKPNP_PHI_BX
-#define EKPNP_PHI_BX 256  // tuning knob
-#endif
-  const int bx = c.p.nx >= EKPNP_PHI_BX ? EKPNP_PHI_BX : 64;
+  const int bx = c.p.nx >= 256 ? 256 : 64;
   const int nxb = (c.p.nx + bx - 1) / bx;
   const bool small = c.nloc < (size_t)2 * 1024 * 1024;
   const int zchunk = small ? 1 : PHI_ZCHUNK_LARGE;

@@ -148,6 +148,7 @@ static int dev_alloc(Ctx& c, void** ptr, size_t bytes) {
 static int validate(const ekpnp_params* p, int rank, int nranks, std::string& err) {
   if (!p) { err = "params is NULL"; return EKPNP_ERR_INVALID; }
   if (p->nx < 1 || p->ny < 1 || p->nz < 4) { err = "grid must be at least 1 x 1 x 4"; return EKPNP_ERR_INVALID; }
+  if (p->ny > 65535) { err = "ny must be at most 65535 (a grid dimension of the wall and halo kernels)"; return EKPNP_ERR_INVALID; }
   if (p->n_lattices != 1 && p->n_lattices != 3 && p->n_lattices != 4) { err = "n_lattices must be 1, 3 or 4"; return EKPNP_ERR_INVALID; }
   if (p->n_lattices < 4 && p->Ra != 0.0) { err = "n_lattices < 4 requires Ra == 0 (temperature feeds the buoyancy force, LBM.cu:637)"; return EKPNP_ERR_INVALID; }
   if (p->n_lattices == 1 && p->chargeinf != 0.0) { err = "n_lattices == 1 requires chargeinf == 0"; return EKPNP_ERR_INVALID; }

@@ -62,6 +62,9 @@ def test_invalid_arguments_return_errors_not_exit(pkg):
     assert lib.ekpnp_create(C.byref(p), C.byref(h)) == 1
     p = pkg.default_params(8, 8, 9)
     assert lib.ekpnp_create_slab(C.byref(p), 0, 2, C.byref(h)) == 1  # nz % nranks
+    p = pkg.default_params(8, 70000, 8)
+    assert lib.ekpnp_create(C.byref(p), C.byref(h)) == 1
+    assert b"ny" in lib.ekpnp_last_error(None)
     assert lib.ekpnp_step(None, 1) == 1
     assert lib.ekpnp_destroy(None) == 1
 

@@ -248,6 +248,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
     const int row_e = (c.z0 + c.nzl == p->nz) ? c.nzl - 2 : c.nzl - 1;
     c.slab_m = row_e - c.slab_row_a + 1;
     if ((rc = dev_alloc(c, (void**)&c.slab_u, (size_t)c.slab_m * nmodes * sizeof(double)))) return bail(rc);
+    if ((rc = dev_alloc(c, (void**)&c.slab_w, (size_t)c.slab_m * nmodes * sizeof(double)))) return bail(rc);
     for (int k = 0; k < 2; ++k)
       if ((rc = dev_alloc(c, (void**)&c.u1um[k], 2 * nmodes * sizeof(double)))) return bail(rc);
     if ((rc = dev_alloc(c, (void**)&c.edge_local, 4 * nmodes * sizeof(double)))) return bail(rc);
@@ -293,6 +294,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (c.cprime) (void)hipFree(c.cprime);
   drop_graph(c);
   if (c.slab_u) (void)hipFree(c.slab_u);
+  if (c.slab_w) (void)hipFree(c.slab_w);
   if (c.u1um[0]) (void)hipFree(c.u1um[0]);
   if (c.u1um[1]) (void)hipFree(c.u1um[1]);
   if (c.edge_local) (void)hipFree(c.edge_local);

@@ -163,6 +163,7 @@ struct Ctx {
   // distributed tridiagonal (slab contexts)
   int slab_row_a = 0, slab_m = 0;  // first unknown row (local plane) and number of unknown rows
   double* slab_u = nullptr;        // u = A^-1 e_1, [slab_m][modes]
+  double* slab_w = nullptr;        // forward elimination of e_1, [slab_m][modes]
   double* u1um[2] = {};            // (u_1, u_m) of an edge slab (nzl-1 rows) / a middle slab (nzl rows)
   double* edge_local = nullptr;    // [4][modes]
   double* edge_all = nullptr;      // [nranks][4][modes]

@@ -253,11 +253,21 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
 // m = e-a+1 of them).  With g_lo = x[a-1] and g_hi = x[e+1] (0 at a wall, the neighbour's edge
 // value at a slab interface) the local rows read  A x = r - g_lo e_1 - g_hi e_m,  A = tridiag(1,b,1),
 // hence  x = p - g_lo u - g_hi v,  p = A^-1 r,  u = A^-1 e_1,  v_k = u_{m+1-k}.
-// Stage 1 computes p (local Thomas) and publishes (p_1, p_m); after an all-gather every rank
-// solves the same 2(P-1)-unknown interface system per mode and corrects its rows.
+// Only the edge values (p_1, p_m) are needed to couple the slabs, so the Thomas solve is SPLIT
+// around the exchange instead of being followed by a correction pass over all rows:
+//   stage 1  forward elimination d' of the local rows (kept in the spectrum), p_m = d'_m and
+//            p_1 = u . r (A is symmetric, so e_1^T A^-1 r = u^T r);
+//   all-gather of (p_1, p_m); every rank solves the same 2(P-1)-unknown interface system per mode;
+//   stage 2  back substitution of the TRUE system A x = r - g_lo e_1 - g_hi e_m: by linearity its
+//            eliminated right-hand side is d'_k - g_lo w_k - g_hi c'_m [k = m], where w is the
+//            forward elimination of e_1 (w_1 = c'_1, w_k = -w_{k-1} c'_k, a table like u).
+// Per solve this reads the spectrum twice and writes it twice (like the single-context Thomas
+// solve) instead of three times each.
 
-// u = A^-1 e_1 for an m-row block; stores the full vector and (u_1, u_m).
-__global__ void k_slab_unit_response(const double* __restrict__ cprime, int m, int nmodes, double* __restrict__ u, double* __restrict__ u1um) {
+// u = A^-1 e_1 for an m-row block; stores the full vector, (u_1, u_m) and, if asked for, the
+// forward elimination w of e_1.
+__global__ void k_slab_unit_response(const double* __restrict__ cprime, int m, int nmodes, double* __restrict__ u, double* __restrict__ u1um,
+                                     double* __restrict__ w) {
   const int md = blockIdx.x * blockDim.x + threadIdx.x;
   if (md >= nmodes) return;
   const long long ms = nmodes;
@@ -269,6 +279,7 @@ __global__ void k_slab_unit_response(const double* __restrict__ cprime, int m, i
   for (int k = 1; k <= m; ++k) {
     d = ((k == 1 ? 1.0 : 0.0) - d) * cp[(long long)k * ms];
     u[(long long)(k - 1) * ms + md] = d;
+    if (w) w[(long long)(k - 1) * ms + md] = d;
   }
   double x = d;
   for (int k = m - 1; k >= 1; --k) {
@@ -279,40 +290,36 @@ __global__ void k_slab_unit_response(const double* __restrict__ cprime, int m, i
   u1um[ms + md] = d;  // u_m = d'_m
 }
 
-// stage 1: local Thomas solve of the owned unknown rows, in place; edges -> edge buffer
+// stage 1: forward elimination of the owned unknown rows, in place; edges -> edge buffer
 // edge layout per rank: [4][nmodes] = p_first.re, p_first.im, p_last.re, p_last.im
-__global__ void k_slab_thomas_local(PArgs a, int row_a, int m, double* __restrict__ edge) {
+__global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __restrict__ u, double* __restrict__ edge) {
   const int md = blockIdx.x * blockDim.x + threadIdx.x;
   const long long ms = (long long)a.ny * a.nxh;
   if (md >= ms) return;
   const double dz2 = a.dz * a.dz;
   double2* s = a.spec + md + (long long)row_a * ms;  // local plane of the first unknown row
   const double* cp = a.cprime + md;
-  double dr = 0.0, di = 0.0;
-#pragma unroll 4
+  const double* up = u + md;
+  double dr = 0.0, di = 0.0, p1r = 0.0, p1i = 0.0;
+#pragma unroll 8
   for (int k = 1; k <= m; ++k) {
     const double2 r = s[(long long)(k - 1) * ms];
     const double c = cp[(long long)k * ms];
-    dr = (dz2 * r.x - dr) * c;
-    di = (dz2 * r.y - di) * c;
+    const double uk = up[(long long)(k - 1) * ms];
+    const double rr = dz2 * r.x, ri = dz2 * r.y;
+    p1r += uk * rr;
+    p1i += uk * ri;
+    dr = (rr - dr) * c;
+    di = (ri - di) * c;
     s[(long long)(k - 1) * ms] = make_double2(dr, di);
   }
-  double pr = dr, pi = di;
-  edge[2 * ms + md] = pr;
-  edge[3 * ms + md] = pi;
-#pragma unroll 4
-  for (int k = m - 1; k >= 1; --k) {
-    const double2 d = s[(long long)(k - 1) * ms];
-    const double c = cp[(long long)k * ms];
-    pr = d.x - c * pr;
-    pi = d.y - c * pi;
-    s[(long long)(k - 1) * ms] = make_double2(pr, pi);
-  }
-  edge[md] = pr;
-  edge[ms + md] = pi;
+  edge[md] = p1r;           // p_1 = u . r
+  edge[ms + md] = p1i;
+  edge[2 * ms + md] = dr;   // p_m = d'_m
+  edge[3 * ms + md] = di;
 }
 
-// stage 2: interface system (block tridiagonal, 2x2 blocks, P-1 interfaces) + correction.
+// stage 2: interface system (block tridiagonal, 2x2 blocks, P-1 interfaces) + back substitution.
 // Interface i sits between slab i and i+1: X_i = x_last(slab i), Y_i = x_first(slab i+1):
 //   um_i X_{i-1} + X_i + u1_i Y_i             = p_last(i)
 //   u1_{i+1} X_i + Y_i + um_{i+1} Y_{i+1}     = p_first(i+1)
@@ -320,7 +327,7 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, double* __restric
 constexpr int MAXR = 16;
 __global__ void k_slab_reduce_correct(PArgs a, int rank, int nranks, int row_a, int m, const double* __restrict__ edges_all,
                                       const double* __restrict__ u1um_edge, const double* __restrict__ u1um_mid,
-                                      const double* __restrict__ u) {
+                                      const double* __restrict__ w) {
   const int md = blockIdx.x * blockDim.x + threadIdx.x;
   const long long ms = (long long)a.ny * a.nxh;
   if (md >= ms) return;
@@ -370,16 +377,25 @@ __global__ void k_slab_reduce_correct(PArgs a, int rank, int nranks, int row_a, 
   }
   const double glr = rank > 0 ? Xr[rank - 1] : 0.0, gli = rank > 0 ? Xi[rank - 1] : 0.0;
   const double ghr = rank < nranks - 1 ? Yr[rank] : 0.0, ghi = rank < nranks - 1 ? Yi[rank] : 0.0;
-  // correction of the owned rows: x_k = p_k - g_lo u_k - g_hi u_{m+1-k}
+  // back substitution of A x = r - g_lo e_1 - g_hi e_m from the stored d'
   double2* s = a.spec + md + (long long)row_a * ms;
-#pragma unroll 4
-  for (int k = 1; k <= m; ++k) {
-    const double uk = u[(long long)(k - 1) * ms + md];
-    const double vk = u[(long long)(m - k) * ms + md];
-    double2 p = s[(long long)(k - 1) * ms];
-    p.x -= glr * uk + ghr * vk;
-    p.y -= gli * uk + ghi * vk;
-    s[(long long)(k - 1) * ms] = p;
+  const double* cp = a.cprime + md;
+  const double* wp = w + md;
+  double xr, xi;
+  {
+    const double2 d = s[(long long)(m - 1) * ms];
+    const double c = cp[(long long)m * ms], wk = wp[(long long)(m - 1) * ms];
+    xr = (d.x - glr * wk) - ghr * c;
+    xi = (d.y - gli * wk) - ghi * c;
+    s[(long long)(m - 1) * ms] = make_double2(xr, xi);
+  }
+#pragma unroll 8
+  for (int k = m - 1; k >= 1; --k) {
+    const double2 d = s[(long long)(k - 1) * ms];
+    const double c = cp[(long long)k * ms], wk = wp[(long long)(k - 1) * ms];
+    xr = (d.x - glr * wk) - c * xr;
+    xi = (d.y - gli * wk) - c * xi;
+    s[(long long)(k - 1) * ms] = make_double2(xr, xi);
   }
 }
 
@@ -401,13 +417,13 @@ void build_cprime(Ctx& c) {
   if (c.slab) {
     const bool edge_rank = (c.rank == 0 || c.rank == c.nranks - 1);
     hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.slab_m, nm, c.slab_u,
-                       edge_rank ? c.u1um[0] : c.u1um[1]);
+                       edge_rank ? c.u1um[0] : c.u1um[1], c.slab_w);
     // (u_1, u_m) of the other slab type, through a scratch vector (set-up only)
     const int m_other = edge_rank ? c.nzl : c.nzl - 1;
     double* tmp = nullptr;
     if (hipMalloc((void**)&tmp, (size_t)m_other * nm * sizeof(double)) == hipSuccess) {
       hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, m_other, nm, tmp,
-                         edge_rank ? c.u1um[1] : c.u1um[0]);
+                         edge_rank ? c.u1um[1] : c.u1um[0], (double*)nullptr);
       (void)hipStreamSynchronize(c.stream);
       (void)hipFree(tmp);
     } else {
@@ -419,14 +435,14 @@ void build_cprime(Ctx& c) {
 void launch_slab_thomas_local(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
-  hipLaunchKernelGGL(k_slab_thomas_local, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.edge_local);
+  hipLaunchKernelGGL(k_slab_thomas_local, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, c.edge_local);
 }
 
 void launch_slab_reduce_correct(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
   hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.slab_row_a, c.slab_m,
-                     c.edge_all, c.u1um[0], c.u1um[1], c.slab_u);
+                     c.edge_all, c.u1um[0], c.u1um[1], c.slab_w);
 }
 
 void launch_phi_halo_pack(Ctx& c) {

@@ -297,13 +297,13 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
 // hence  x = p - g_lo u - g_hi v,  p = A^-1 r,  u = A^-1 e_1,  v_k = u_{m+1-k}.
 // Only the edge values (p_1, p_m) are needed to couple the slabs, so the Thomas solve is SPLIT
 // around the exchange instead of being followed by a correction pass over all rows:
-//   stage 1  forward elimination d' of the local rows (kept in the spectrum), p_m = d'_m and
-//            p_1 = u . r (A is symmetric, so e_1^T A^-1 r = u^T r);
+//   stage 1  forward elimination d' of the local rows (every TRI_BS-th row of it kept in the
+//            spectrum), p_m = d'_m and p_1 = u . r (A is symmetric, so e_1^T A^-1 r = u^T r);
 //   all-gather of (p_1, p_m); every rank solves the same 2(P-1)-unknown interface system per mode;
 //   stage 2  back substitution of the TRUE system A x = r - g_lo e_1 - g_hi e_m: by linearity its
 //            eliminated right-hand side is d'_k - g_lo w_k - g_hi c'_m [k = m], where w is the
 //            forward elimination of e_1 (w_1 = c'_1, w_k = -w_{k-1} c'_k, a table like u).
-// Per solve this reads the spectrum twice and writes it twice (like the single-context Thomas
+// Per solve this reads the spectrum twice and writes it once (like the single-context Thomas
 // solve) instead of three times each.
 
 // u = A^-1 e_1 for an m-row block; stores the full vector, (u_1, u_m) and, if asked for, the
@@ -353,7 +353,7 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __r
     p1i += uk * ri;
     dr = (rr - dr) * c;
     di = (ri - di) * c;
-    s[(long long)(k - 1) * ms] = make_double2(dr, di);
+    if ((k & (TRI_BS - 1)) == 0) s[(long long)(k - 1) * ms] = make_double2(dr, di);  // checkpoint, as in k_tridiag
   }
   edge[md] = p1r;           // p_1 = u . r
   edge[ms + md] = p1i;
@@ -419,25 +419,54 @@ __global__ void k_slab_reduce_correct(PArgs a, int rank, int nranks, int row_a, 
   }
   const double glr = rank > 0 ? Xr[rank - 1] : 0.0, gli = rank > 0 ? Xi[rank - 1] : 0.0;
   const double ghr = rank < nranks - 1 ? Yr[rank] : 0.0, ghi = rank < nranks - 1 ? Yi[rank] : 0.0;
-  // back substitution of A x = r - g_lo e_1 - g_hi e_m from the stored d'
+  // back substitution of A x = r - g_lo e_1 - g_hi e_m; d' is recomputed block by block from the
+  // checkpoints stage 1 left in every TRI_BS-th row (as in k_tridiag)
   double2* s = a.spec + md + (long long)row_a * ms;
   const double* cp = a.cprime + md;
   const double* wp = w + md;
-  double xr, xi;
-  {
-    const double2 d = s[(long long)(m - 1) * ms];
-    const double c = cp[(long long)m * ms], wk = wp[(long long)(m - 1) * ms];
-    xr = (d.x - glr * wk) - ghr * c;
-    xi = (d.y - gli * wk) - ghi * c;
-    s[(long long)(m - 1) * ms] = make_double2(xr, xi);
-  }
-#pragma unroll 8
-  for (int k = m - 1; k >= 1; --k) {
-    const double2 d = s[(long long)(k - 1) * ms];
-    const double c = cp[(long long)k * ms], wk = wp[(long long)(k - 1) * ms];
-    xr = (d.x - glr * wk) - c * xr;
-    xi = (d.y - gli * wk) - c * xi;
-    s[(long long)(k - 1) * ms] = make_double2(xr, xi);
+  const double dz2 = a.dz * a.dz;
+  double xr = 0.0, xi = 0.0;
+  for (int khi = m; khi >= 1;) {
+    const int klo = ((khi - 1) / TRI_BS) * TRI_BS + 1;
+    double2 d[TRI_BS];
+    double c[TRI_BS], wv[TRI_BS];
+    double2 prev = make_double2(0.0, 0.0);
+    if (klo > 1) prev = s[(long long)(klo - 2) * ms];
+#pragma unroll
+    for (int i = 0; i < TRI_BS; ++i) {
+      const int k = klo + i;
+      if (k <= khi) {
+        d[i] = s[(long long)(k - 1) * ms];
+        c[i] = cp[(long long)k * ms];
+        wv[i] = wp[(long long)(k - 1) * ms];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TRI_BS; ++i) {
+      const int k = klo + i;
+      if (k <= khi) {
+        if (i != TRI_BS - 1) {
+          d[i].x = (dz2 * d[i].x - prev.x) * c[i];
+          d[i].y = (dz2 * d[i].y - prev.y) * c[i];
+        }
+        prev = d[i];
+      }
+    }
+#pragma unroll
+    for (int i = TRI_BS - 1; i >= 0; --i) {
+      const int k = klo + i;
+      if (k <= khi) {
+        if (k == m) {
+          xr = (d[i].x - glr * wv[i]) - ghr * c[i];
+          xi = (d[i].y - gli * wv[i]) - ghi * c[i];
+        } else {
+          xr = (d[i].x - glr * wv[i]) - c[i] * xr;
+          xi = (d[i].y - gli * wv[i]) - c[i] * xi;
+        }
+        s[(long long)(k - 1) * ms] = make_double2(xr, xi);
+      }
+    }
+    khi = klo - 1;
   }
 }
 

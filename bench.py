@@ -275,6 +275,13 @@ def main():
         k_avg_ms = k_ms / max(1, n_launch)
         bytes_per_launch = b_alg_lbm(nl) * k_nodes
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+        # secondary denominator: what a plain contiguous copy reaches on THIS device, now
+        copy_gbs = None
+        try:
+            free_now, _ = torch.cuda.mem_get_info()
+            copy_gbs = sol.copy_bandwidth(min(2 << 30, free_now // 4))
+        except Exception as exc:  # e.g. no room for the scratch buffers next to a 276 GB lattice
+            print(f"copy-bandwidth probe skipped: {exc}", file=sys.stderr)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
@@ -317,6 +324,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "copy_GBps": round(copy_gbs, 1) if copy_gbs else None,
+                "frac_of_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                 "bytes_per_node": b_alg_lbm(nl),
                 "nodes_per_launch": int(k_nodes),
                 "launches_per_step": launches_per_step,

@@ -392,6 +392,40 @@ extern "C" int ekpnp_set_time(ekpnp_ctx* ctx, double t) {
 extern "C" size_t ekpnp_device_bytes(const ekpnp_ctx* ctx) { return ctx ? ctx->c.bytes : 0; }
 extern "C" int ekpnp_graph_state(const ekpnp_ctx* ctx) { return !ctx ? 0 : ctx->c.graph_failed ? -1 : ctx->c.graph2 ? 1 : 0; }
 
+extern "C" int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s) {
+  NEEDCTX(ctx);
+  if (!gb_per_s || bytes < 16) return fail(c, "ekpnp_copy_bandwidth: bad arguments");
+  bytes &= ~(size_t)15;
+  void *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&src, bytes);
+  if (e == hipSuccess) e = hipMalloc(&dst, bytes);
+  if (e == hipSuccess) e = hipMemsetAsync(src, 0, bytes, c.stream);
+  if (e == hipSuccess) e = hipMemsetAsync(dst, 0, bytes, c.stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  float best = 0.0f;
+  if (e == hipSuccess) {
+    launch_copy16(c, src, dst, bytes);  // warm-up
+    for (int rep = 0; rep < 5 && e == hipSuccess; ++rep) {
+      e = hipEventRecord(e0, c.stream);
+      launch_copy16(c, src, dst, bytes);
+      if (e == hipSuccess) e = hipEventRecord(e1, c.stream);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      float ms = 0.0f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (e == hipSuccess && (best == 0.0f || ms < best)) best = ms;
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (src) (void)hipFree(src);
+  if (dst) (void)hipFree(dst);
+  HIPCHK(c, e);
+  *gb_per_s = best > 0.0f ? 2.0 * (double)bytes / ((double)best * 1e6) : 0.0;
+  return EKPNP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Poisson
 

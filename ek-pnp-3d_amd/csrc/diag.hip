@@ -102,4 +102,15 @@ void launch_max_abs_diff(Ctx& c, const double* p, const double* q, double* scrat
   hipLaunchKernelGGL((k_final<true>), dim3(1), dim3(256), 0, c.stream, scratch, nb, scratch + DIAG_BLOCKS);
 }
 
+// plain contiguous copy, 16 bytes per lane (the shape tools/stream_probe.hip calls "copy 16B/lane")
+__global__ void k_copy16(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+void launch_copy16(Ctx& c, const void* src, void* dst, size_t bytes) {
+  const size_t n = bytes / sizeof(double2);
+  hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, (const double2*)src, (double2*)dst, n);
+}
+
 }  // namespace ekpnp

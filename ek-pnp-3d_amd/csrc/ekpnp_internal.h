@@ -120,6 +120,7 @@ constexpr int DIAG_SCRATCH = 1024 + 8;
 void launch_current(Ctx&, double* scratch);
 void launch_umax(Ctx&, double* scratch);
 void launch_max_abs_diff(Ctx&, const double* p, const double* q, double* scratch);
+void launch_copy16(Ctx&, const void* src, void* dst, size_t bytes);
 
 struct Ctx {
   ekpnp_params p{};

@@ -111,6 +111,7 @@ def load_library():
         "ekpnp_kernel_timing_get": (i32, [ctx, C.POINTER(i32), pd, C.POINTER(C.c_int64)]),
         "ekpnp_device_bytes": (sz, [ctx]),
         "ekpnp_graph_state": (i32, [ctx]),
+        "ekpnp_copy_bandwidth": (i32, [ctx, sz, pd]),
         "ekpnp_halo_buffer": (i32, [ctx, i32, C.POINTER(C.c_void_p), C.POINTER(sz)]),
         "ekpnp_halo_pack": (i32, [ctx]),
         "ekpnp_halo_unpack": (i32, [ctx]),
@@ -224,6 +225,12 @@ class Solver:
 
     def device_bytes(self) -> int:
         return int(self._L.ekpnp_device_bytes(self._h))
+
+    def copy_bandwidth(self, nbytes: int = 1 << 32) -> float:
+        """GB/s (read + write) of a plain contiguous device copy: the measured streaming ceiling."""
+        v = C.c_double()
+        self._ck(self._L.ekpnp_copy_bandwidth(self._h, int(nbytes), C.byref(v)))
+        return v.value
 
     # -- fields -----------------------------------------------------------------------------
     def get_field(self, name: str) -> np.ndarray:

@@ -196,6 +196,10 @@ int ekpnp_kernel_timing_enable(ekpnp_ctx* ctx, int enable);
 int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* total_ms,
                             int64_t* nodes_per_launch);
 size_t ekpnp_device_bytes(const ekpnp_ctx* ctx);
+/* Streaming-copy rate of this device in GB/s (read + write bytes / time) of a plain contiguous
+ * copy of `bytes` bytes on the context's stream: the secondary denominator SURVEY.md 8(d) asks
+ * for next to the 8 TB/s spec figure.  Allocates and frees 2 x `bytes` of scratch. */
+int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
 /* 1: ekpnp_step holds an instantiated 2-step hipGraph, 0: none yet, -1: capture failed (eager). */
 int ekpnp_graph_state(const ekpnp_ctx* ctx);
 

@@ -206,3 +206,14 @@ def test_save_scalar_names_and_bytes(pkg, tmp_path):
         assert np.array_equal(np.fromfile(tmp_path / "ux0037.bin"), a.ravel())
         s.save_scalar(str(tmp_path / "ux"), "ux", 5, nsteps=99)
         assert (tmp_path / "ux05.bin").exists()
+
+
+def test_copy_bandwidth_probe(pkg):
+    """ekpnp_copy_bandwidth: the measured streaming ceiling bench.py reports next to the 8 TB/s
+    spec figure.  A 256 MiB copy on an MI355X is far above 500 GB/s and cannot exceed the spec."""
+    p = pkg.default_params(16, 8, 9)
+    with pkg.Solver(p) as s:
+        bw = s.copy_bandwidth(256 << 20)
+        assert 500.0 < bw < 8000.0, bw
+        with pytest.raises(pkg.EkpnpError):
+            s.copy_bandwidth(0)

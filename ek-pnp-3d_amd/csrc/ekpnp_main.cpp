@@ -35,7 +35,8 @@ int main(int argc, char* argv[]) {
   // LBM.h:32-35,122-125
   int nx = 50, ny = 8, nz = 51;
   unsigned nsteps = 1000, nsave = 0, print_current = 50;
-  int flag = 0;  // 1: read previous data (main.cu:161)
+  int flag = 0;  // 1: read previous data (main.cu:161); 2: from the lossless data_end.bin
+  int binary_state = 0;  // also write data_end.bin (ekpnp_save_state) at the end
   int lattices = 4;
   std::string out = ".";
   double exf = 0.0, uw = 0.0, chargeinf = -1.0, Ra = -1.0, TH = -1.0;
@@ -52,6 +53,7 @@ int main(int argc, char* argv[]) {
     else if ((v = val("--nsave"))) nsave = (unsigned)std::atoi(v);
     else if ((v = val("--print-current"))) print_current = (unsigned)std::atoi(v);
     else if ((v = val("--read-previous"))) flag = std::atoi(v);
+    else if ((v = val("--binary-state"))) binary_state = std::atoi(v);
     else if ((v = val("--lattices"))) lattices = std::atoi(v);
     else if ((v = val("--out"))) out = v;
     else if ((v = val("--exf"))) exf = std::atof(v);
@@ -61,7 +63,8 @@ int main(int argc, char* argv[]) {
     else if ((v = val("--TH"))) TH = std::atof(v);
     else {
       std::fprintf(stderr,
-                   "usage: ekpnp_main [--nx N --ny N --nz N] [--steps N] [--nsave N] [--print-current N] [--read-previous 0|1]\n"
+                   "usage: ekpnp_main [--nx N --ny N --nz N] [--steps N] [--nsave N] [--print-current N] [--read-previous 0|1|2]\n"
+                   "                  [--binary-state 0|1]\n"
                    "                  [--lattices 1|3|4] [--exf F --uw U --chargeinf C --Ra R --TH T] [--out DIR]\n");
       return 2;
     }
@@ -99,10 +102,14 @@ int main(int argc, char* argv[]) {
   std::printf("      device memory held by the solver: %.1f MiB\n\n", (double)ekpnp_device_bytes(ctx) / (1024.0 * 1024.0));
 
   const std::string f_data = out + "/data.dat", f_umax = out + "/umax.dat", f_end = out + "/data_end.dat";
+  const std::string f_bin = out + "/data_end.bin";
   double t = 0.0;
   if (flag == 1) {  // main.cu:161-164
     std::printf("Reading previous data...\n");
     CK(ekpnp_read_data(ctx, f_end.c_str(), &t));
+  } else if (flag == 2) {  // the same restart from the lossless file
+    std::printf("Reading previous data (binary)...\n");
+    CK(ekpnp_read_state(ctx, f_bin.c_str(), &t));
   } else {  // main.cu:165-171
     std::printf("Initializing...\n");
     CK(ekpnp_initialization(ctx));
@@ -142,6 +149,7 @@ int main(int argc, char* argv[]) {
 
   CK(ekpnp_save_data_tecplot(ctx, f_data.c_str(), 1, t, 1));  // main.cu:253
   CK(ekpnp_save_data_end(ctx, f_end.c_str(), 0, t));          // main.cu:256-257
+  if (binary_state) CK(ekpnp_save_state(ctx, f_bin.c_str(), t));
   CK(ekpnp_destroy(ctx));                                     // main.cu:264-290
   return 0;
 }

@@ -164,6 +164,72 @@ extern "C" int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time) {
   return EKPNP_OK;
 }
 
+// ---- lossless binary state (no reference counterpart beyond the save_data_end / read_data pair) ----
+namespace {
+struct StateHeader {
+  char magic[8];
+  int32_t nx, ny, nz, z0, nzl, nfields;
+  double time;
+};
+static_assert(sizeof(StateHeader) == 40, "state header layout");
+constexpr size_t STATE_CHUNK = (size_t)4 << 20;  // doubles per bounce-buffer transfer (32 MiB)
+}  // namespace
+
+extern "C" int ekpnp_save_state(ekpnp_ctx* ctx, const char* path, double time) {
+  NEEDCTX(ctx);
+  if (!path) return fail(c, "NULL path");
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return fail(c, "cannot open state file");
+  StateHeader h{};
+  std::memcpy(h.magic, "EKPNPST1", 8);
+  h.nx = c.p.nx; h.ny = c.p.ny; h.nz = c.p.nz; h.z0 = c.z0; h.nzl = c.nzl; h.nfields = EKPNP_NFIELDS;
+  h.time = time;
+  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+  std::vector<double> buf(c.nloc < STATE_CHUNK ? c.nloc : STATE_CHUNK);
+  hipError_t e = hipStreamSynchronize(c.stream);
+  for (int i = 0; ok && e == hipSuccess && i < EKPNP_NFIELDS; ++i)
+    for (size_t o = 0; ok && e == hipSuccess && o < c.nloc; o += buf.size()) {
+      const size_t n = c.nloc - o < buf.size() ? c.nloc - o : buf.size();
+      e = hipMemcpy(buf.data(), c.fld[i] + o, n * sizeof(double), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) ok = std::fwrite(buf.data(), sizeof(double), n, f) == n;
+    }
+  ok = (std::fclose(f) == 0) && ok;
+  HIPCHK(c, e);
+  return ok ? EKPNP_OK : fail(c, "write error on state file");
+}
+
+extern "C" int ekpnp_read_state(ekpnp_ctx* ctx, const char* path, double* time) {
+  NEEDCTX(ctx);
+  if (!path || !time) return fail(c, "NULL pointer");
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(c, "cannot open state file");
+  StateHeader h{};
+  if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "EKPNPST1", 8) != 0) {
+    std::fclose(f);
+    return fail(c, "not an EKPNPST1 state file");
+  }
+  if (h.nx != c.p.nx || h.ny != c.p.ny || h.nz != c.p.nz || h.z0 != c.z0 || h.nzl != c.nzl || h.nfields != EKPNP_NFIELDS) {
+    std::fclose(f);
+    return fail(c, "state file was written for a different lattice or slab");
+  }
+  std::vector<double> buf(c.nloc < STATE_CHUNK ? c.nloc : STATE_CHUNK);
+  bool ok = true;
+  hipError_t e = hipStreamSynchronize(c.stream);
+  for (int i = 0; ok && e == hipSuccess && i < EKPNP_NFIELDS; ++i)
+    for (size_t o = 0; ok && e == hipSuccess && o < c.nloc; o += buf.size()) {
+      const size_t n = c.nloc - o < buf.size() ? c.nloc - o : buf.size();
+      ok = std::fread(buf.data(), sizeof(double), n, f) == n;
+      if (ok) e = hipMemcpy(c.fld[i] + o, buf.data(), n * sizeof(double), hipMemcpyHostToDevice);
+    }
+  std::fclose(f);
+  HIPCHK(c, e);
+  if (!ok) return fail(c, "state file is shorter than the lattice");
+  *time = h.time;
+  c.t = h.time;
+  c.rhs_ready = false;
+  return EKPNP_OK;
+}
+
 extern "C" int ekpnp_compute_parameters(const ekpnp_params* p, double* T, double* M, double* C, double* Fe, double* Pr) {
   if (!p) return EKPNP_ERR_INVALID;
   // LBM.cu:2440-2444, same expressions (charge0_host there is chargeinf, LBM.cu:2436)

@@ -135,6 +135,8 @@ def load_library():
         "ekpnp_save_data_tecplot": (i32, [ctx, C.c_char_p, i32, dbl, i32]),
         "ekpnp_save_data_end": (i32, [ctx, C.c_char_p, i32, dbl]),
         "ekpnp_read_data": (i32, [ctx, C.c_char_p, pd]),
+        "ekpnp_save_state": (i32, [ctx, C.c_char_p, dbl]),
+        "ekpnp_read_state": (i32, [ctx, C.c_char_p, pd]),
         "ekpnp_compute_parameters": (i32, [C.POINTER(Params), pd, pd, pd, pd, pd]),
         "ekpnp_save_scalar": (i32, [ctx, C.c_char_p, i32, C.c_uint, C.c_uint]),
     }
@@ -311,6 +313,15 @@ class Solver:
     def read_data(self, path: str) -> float:
         t = C.c_double()
         self._ck(self._L.ekpnp_read_data(self._h, os.fsencode(path), C.byref(t)))
+        return t.value
+
+    def save_state(self, path: str, time: float = 0.0):
+        """Lossless binary variant of save_data_end (raw FP64 fields of the owned planes)."""
+        self._ck(self._L.ekpnp_save_state(self._h, os.fsencode(path), float(time)))
+
+    def read_state(self, path: str) -> float:
+        t = C.c_double()
+        self._ck(self._L.ekpnp_read_state(self._h, os.fsencode(path), C.byref(t)))
         return t.value
 
     # -- z-slab pieces (driven by slab.py) ---------------------------------------------------

@@ -179,6 +179,14 @@ int ekpnp_save_data_end(ekpnp_ctx* ctx, const char* path, int append, double tim
 /* void read_data(double* time, r, c, cn, fi, u, v, w, ex, ey, ez, temp) — LBM.h:160,
  * LBM.cu:2632-2671: fills the 11 fields from a save_data_end file (main.cu:161-164). */
 int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time);
+/* Lossless variant of the save_data_end / read_data pair (the reference's
+ * restart file keeps 6 decimals, LBM.cu:2619-2622, and overwrites the wall values of rho, c, cn, u
+ * by their extrapolation, LBM.cu:2596-2611): the 11 macroscopic fields of the owned planes as
+ * raw little-endian FP64 behind a 40-byte header {"EKPNPST1", nx, ny, nz, z0, nz_local, 11,
+ * time}.  Restart is the reference's: ekpnp_read_state, then ekpnp_init_equilibrium
+ * (main.cu:161-175).  Slab contexts write / read their own planes (one file per rank). */
+int ekpnp_save_state(ekpnp_ctx* ctx, const char* path, double time);
+int ekpnp_read_state(ekpnp_ctx* ctx, const char* path, double* time);
 
 /* void compute_parameters(double* T, double* M, double* C, double* Fe, double* Pr) — LBM.h:171,
  * LBM.cu:2419-2446: the dimensionless groups main.cu:38 computes for its banner.  Pure host

@@ -192,6 +192,12 @@ def test_cpp_driver_reproduces_the_library_calls(pkg, O, tmp_path):
     r2 = subprocess.run([exe, "--nx", str(shape[0]), "--ny", str(shape[1]), "--nz", str(shape[2]), "--steps", "2", "--read-previous", "1",
                          "--out", str(out)], capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0 and "Reading previous data" in r2.stdout, r2.stderr
+    # ... and the lossless variant: write data_end.bin, restart from it
+    geo = ["--nx", str(shape[0]), "--ny", str(shape[1]), "--nz", str(shape[2]), "--out", str(out)]
+    r4 = subprocess.run([exe, *geo, "--steps", "4", "--binary-state", "1"], capture_output=True, text=True, timeout=300)
+    assert r4.returncode == 0 and os.path.getsize(out / "data_end.bin") == 40 + 11 * 8 * shape[0] * shape[1] * shape[2], r4.stderr
+    r5 = subprocess.run([exe, *geo, "--steps", "2", "--read-previous", "2"], capture_output=True, text=True, timeout=300)
+    assert r5.returncode == 0 and "(binary)" in r5.stdout, r5.stderr
     r3 = subprocess.run([exe, "--nx", "8", "--ny", "8", "--nz", "2"], capture_output=True, text=True, timeout=60)
     assert r3.returncode != 0 and "failed" in r3.stderr  # errors are reported, never a crash
 
@@ -217,3 +223,43 @@ def test_copy_bandwidth_probe(pkg):
         assert 500.0 < bw < 8000.0, bw
         with pytest.raises(pkg.EkpnpError):
             s.copy_bandwidth(0)
+
+
+def test_binary_state_is_lossless(pkg, O, tmp_path):
+    """ekpnp_save_state / ekpnp_read_state ("lossless binary variant"): the 11
+    fields come back bit for bit, the run restarted from the file (read_state + init_equilibrium,
+    main.cu:161-175) continues exactly like one restarted from the same fields in memory, and the
+    reference's text file (6 decimals) does not."""
+    po = O.default_params(20, 6, 11)
+    po.pb_iterations = 5
+    p = pkg.Params()
+    for n, _ in p._fields_:
+        setattr(p, n, getattr(po, n))
+    path = str(tmp_path / "state.bin")
+    with pkg.Solver(p) as s:
+        s.initialization()
+        s.set_fields(O.perturb_fields(po, s.fields())); s.fast_Poisson(); s.init_equilibrium()
+        s.step(7)
+        saved = s.fields()
+        s.save_state(path, 7 * p.dt)
+        s.save_data_end(str(tmp_path / "data_end.dat"), 7 * p.dt)
+        s.init_equilibrium(); s.step(3)          # restart in memory: fields -> equilibrium -> run on
+        want = s.fields()
+    assert os.path.getsize(path) == 40 + 11 * 8 * 20 * 6 * 11
+    with pkg.Solver(p) as s:
+        t = s.read_state(path)
+        assert t == 7 * p.dt
+        got = s.fields()
+        for k in saved:
+            assert np.array_equal(got[k], saved[k]), k
+        s.init_equilibrium(); s.step(3)
+        cont = s.fields()
+        for k in want:
+            assert np.array_equal(cont[k], want[k]), k
+    with pkg.Solver(p) as s:
+        s.read_data(str(tmp_path / "data_end.dat"))
+        assert not np.array_equal(s.get_field("phi"), saved["phi"])  # the text format is lossy
+    q = p.copy(); q.nz = 12; q.Lz = (q.nz - 1) * q.dz
+    with pkg.Solver(q) as s:
+        with pytest.raises(pkg.EkpnpError):
+            s.read_state(path)                   # written for a different lattice

@@ -147,8 +147,8 @@ def cpu_baseline(nl: int, budget_s: float = 15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--ic", default="perturbed", choices=["perturbed", "uniform"])
     ap.add_argument("--pb-iterations", type=int, default=None)

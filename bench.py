@@ -144,6 +144,39 @@ def cpu_baseline(nl: int, budget_s: float = 15.0):
     }
 
 
+def spawn_ranks(n: int, argv: list) -> int:
+    """`python bench.py --gpus N` invoked plainly (N > 1): start the N ranks the way the driver
+    does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    arguments>`) as a child process, pass its stderr through, print rank 0's ONE JSON line on our
+    stdout and return the child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")             # the ranks are GPU-bound; torchrun would set it anyway (and say so)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in child.stdout:
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}") and '"metric"' in t:
+            line = t
+        elif t:
+            print(ln, end="", file=sys.stderr)  # anything else a rank wrote to stdout is not ours to publish
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,14 +194,19 @@ def main():
                     help="N=1 only: run the multi-rank code path (split calls + RCCL exchanges, the ring closing on the same rank)")
     args = ap.parse_args()
 
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet
+        # (no torch import even); the ranks are CHILD processes, never an exec.
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or run it plainly")
+
+    import torch
+
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)

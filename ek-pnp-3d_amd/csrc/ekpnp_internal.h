@@ -92,6 +92,7 @@ struct PArgs {
 };
 
 struct Ctx;
+struct Team;
 
 // lbm_kernels.hip
 void launch_init_fields(Ctx&);
@@ -124,6 +125,9 @@ void launch_copy16(Ctx&, const void* src, void* dst, size_t bytes);
 
 struct Ctx {
   ekpnp_params p{};
+  int device = 0;              // HIP device the context was created on (current device of every call into it)
+  Team* team = nullptr;        // slab contexts: the exchange domain that moves its halos (slab_team.hip), or null
+  int team_slot = 0;           // index of this context among the team's local slabs
   int rank = 0, nranks = 1;
   bool slab = false;           // created by ekpnp_create_slab: driven through the split calls + a transport
   int nzl = 0, z0 = 0, nxh = 0;
@@ -190,6 +194,23 @@ struct Ctx {
   KArgs kargs() const;
   PArgs pargs() const;
 };
+
+// slab_team.hip: the reference's verbs on a slab context whose team moves the halos itself
+// (ekpnp_slab_attach_comm).  Each returns EKPNP_ERR_INVALID with a message if the context's team
+// is an in-process group (those are driven through ekpnp_group_*).
+int team_ctx_stream_collide_save(Ctx&);
+int team_ctx_fast_poisson(Ctx&);
+int team_ctx_step(Ctx&, int nsteps);
+int team_ctx_initialization(Ctx&);
+int team_ctx_initialization_converged(Ctx&, double rel_tol, int max_sweeps, int* sweeps, double* residual);
+int team_ctx_reduce(Ctx&, double* value, bool is_max);  // combine a per-slab diagnostic over the ranks
+int team_ctx_turns(Ctx&, int (*fn)(Ctx&, void*), void* arg);  // fn on every slab in rank order (file IO)
+void team_detach(Ctx&);  // called by ekpnp_destroy
+
+// io.hip pieces shared with slab_team.hip (a slab writes / reads its own planes of a whole-lattice file)
+struct TextIoArgs { const char* path; int append; double time; int first; int kind; };  // kind 0 Tecplot, 1 data_end
+int io_write_text_part(Ctx&, const TextIoArgs&);
+int io_read_data_part(Ctx&, const char* path, double* time);
 
 }  // namespace ekpnp
 

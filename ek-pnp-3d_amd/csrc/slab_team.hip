@@ -1,0 +1,901 @@
+// slab_team.hip — the z-slab path's own transport, behind the C ABI.
+//
+// No reference counterpart: the reference is single-GPU (cudaSetDevice(0), main.cu:58).  What is
+// rebuilt here for P slabs is its time loop (main.cu:189-200), its initialization()
+// (LBM.cu:68-109) and its IO / diagnostics surface (LBM.cu:2492-2753), with the three exchanges a
+// z decomposition needs between the split entry points of capi.hip:
+//   HALO  9 c_z=+1 populations of the top plane up, 9 c_z=-1 of the bottom plane down, per lattice;
+//         a RING, because gpu_stream wraps z (LBM.cu:1972,1975);
+//   EDGE  4 interface coefficients per (kx,ky) mode of the distributed tridiagonal, all-gathered;
+//   PHI   one phi plane each way for Ez (poisson.cu:50-55), same ring.
+//
+// A Team is the set of slab contexts ONE process drives plus the means to reach the others:
+//   * one process per GPU (bench.py under torch.distributed.run, an MPI host ...): one local slab,
+//     ncclCommInitRank from an id the host distributes        -> ekpnp_slab_attach_comm;
+//   * one process, N GPUs (ekpnp_main --gpus N): all slabs local, ncclCommInitAll, or plain
+//     hipMemcpyPeerAsync between the slabs' buffers            -> ekpnp_group_create.
+// Transfers run on a per-slab COMM STREAM of the highest priority the device offers; the compute
+// stream and the comm stream are ordered by events only (ready: buffers packed / consumed, done:
+// data landed), so the HALO exchange overlaps the collision of the slab's interior planes:
+//   boundary planes -> pack -> [comm: ring] || interior planes -> wait(done) -> unpack.
+// RCCL is bound lazily (dlopen of librccl.so.1) so that single-GPU hosts never load it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ekpnp_internal.h"
+
+namespace ekpnp {
+
+// ---- librccl, bound on first use ---------------------------------------------------------------
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Rccl* rccl(std::string& err) {
+  static Rccl r;
+  static bool tried = false;
+  static std::string why;
+  if (!tried) {
+    tried = true;
+    // an already loaded librccl.so.1 (e.g. the copy PyTorch-ROCm ships) is reused by soname
+    r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.handle) r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.handle) {
+      why = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "?");
+    } else {
+      bool ok = true;
+      auto bind = [&](auto& fn, const char* name) {
+        fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(r.handle, name));
+        if (!fn) { ok = false; why = std::string("librccl.so.1 lacks ") + name; }
+      };
+      bind(r.GetUniqueId, "ncclGetUniqueId");
+      bind(r.CommInitRank, "ncclCommInitRank");
+      bind(r.CommInitAll, "ncclCommInitAll");
+      bind(r.CommDestroy, "ncclCommDestroy");
+      bind(r.GroupStart, "ncclGroupStart");
+      bind(r.GroupEnd, "ncclGroupEnd");
+      bind(r.Send, "ncclSend");
+      bind(r.Recv, "ncclRecv");
+      bind(r.AllGather, "ncclAllGather");
+      bind(r.AllReduce, "ncclAllReduce");
+      bind(r.GetErrorString, "ncclGetErrorString");
+      if (!ok) r.handle = nullptr;
+    }
+  }
+  if (!r.handle) { err = why; return nullptr; }
+  return &r;
+}
+
+// ---- the team ------------------------------------------------------------------------------------
+enum { X_HALO = 0, X_PHI = 1, X_EDGE = 2, X_KINDS = 3 };
+
+struct Team {
+  std::vector<ekpnp_ctx*> m;  // the slabs this process drives, ascending rank
+  int nranks = 1;             // slabs of the whole lattice
+  bool all_local = true;      // every rank is in m (rank r is m[r])
+  bool group = false;         // in-process group (ekpnp_group_*): the member contexts do not dispatch on their own
+  int kind = EKPNP_TRANSPORT_COPY;
+  Rccl* nc = nullptr;
+  std::vector<ncclComm_t> comm;
+  std::vector<hipStream_t> cs;                            // comm stream per local slab
+  std::vector<hipEvent_t> ready[X_KINDS], done[X_KINDS];  // per local slab
+  std::vector<double*> red;                               // 2 doubles of device scratch per local slab
+  double t = 0.0;
+  std::string err;
+};
+
+static inline Ctx& S(Team& T, int i) { return T.m[i]->c; }
+
+#define THIP(T, call)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      (T).err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return EKPNP_ERR_HIP;                                                             \
+    }                                                                                   \
+  } while (0)
+#define TNCCL(T, call)                                                                  \
+  do {                                                                                  \
+    ncclResult_t r_ = (call);                                                           \
+    if (r_ != ncclSuccess) {                                                            \
+      (T).err = std::string(#call) + ": " + (T).nc->GetErrorString(r_);                 \
+      return EKPNP_ERR_HIP;                                                             \
+    }                                                                                   \
+  } while (0)
+// a call into one slab's own entry points (capi.hip); its message becomes the team's
+#define TSLAB(T, i, call)                                                               \
+  do {                                                                                  \
+    int rc_ = (call);                                                                   \
+    if (rc_ != EKPNP_OK) {                                                              \
+      (T).err = "slab " + std::to_string(S(T, i).rank) + ": " + S(T, i).err;            \
+      return rc_;                                                                       \
+    }                                                                                   \
+  } while (0)
+
+static int use(Team& T, int i) {
+  THIP(T, hipSetDevice(S(T, i).device));
+  return EKPNP_OK;
+}
+
+static hipError_t xcopy(void* dst, int ddev, const void* src, int sdev, size_t bytes, hipStream_t s) {
+  return ddev == sdev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) : hipMemcpyPeerAsync(dst, ddev, src, sdev, bytes, s);
+}
+
+// the local slabs whose buffers slab i's data is written into (COPY) == whose data lands in slab i's
+// buffers: the ring neighbours, or everybody for the all-gather
+template <class Fn>
+static void for_partners(Team& T, int i, int x, Fn&& fn) {
+  const int n = (int)T.m.size();
+  if (x == X_EDGE) {
+    for (int j = 0; j < n; ++j)
+      if (j != i) fn(j);
+  } else {
+    const int up = (i + 1) % n, dn = (i + n - 1) % n;
+    if (up != i) fn(up);
+    if (dn != i && dn != up) fn(dn);
+  }
+}
+
+// start exchange x: everything the slabs have enqueued so far on their compute streams precedes it
+static int exchange_begin(Team& T, int x) {
+  const int n = (int)T.m.size();
+  int rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    THIP(T, hipEventRecord(T.ready[x][i], S(T, i).stream));
+  }
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    THIP(T, hipStreamWaitEvent(T.cs[i], T.ready[x][i], 0));
+    if (T.kind == EKPNP_TRANSPORT_COPY) {  // slab i's copies write into its partners' receive buffers
+      hipError_t e = hipSuccess;
+      for_partners(T, i, x, [&](int j) { if (e == hipSuccess) e = hipStreamWaitEvent(T.cs[i], T.ready[x][j], 0); });
+      THIP(T, e);
+    }
+  }
+  if (T.kind == EKPNP_TRANSPORT_RCCL) {
+    TNCCL(T, T.nc->GroupStart());
+    for (int i = 0; i < n; ++i) {
+      Ctx& c = S(T, i);
+      if ((rc = use(T, i))) { (void)T.nc->GroupEnd(); return rc; }
+      ncclResult_t r = ncclSuccess;
+      if (x == X_EDGE) {
+        const size_t per = 4 * (size_t)c.p.ny * c.nxh;
+        r = T.nc->AllGather(c.edge_local, c.edge_all, per, ncclDouble, T.comm[i], T.cs[i]);
+      } else {
+        double** b = x == X_HALO ? c.halo : c.phi_halo;
+        const size_t cnt = x == X_HALO ? c.halo_doubles : c.plane;
+        const int up = (c.rank + 1) % T.nranks, dn = (c.rank + T.nranks - 1) % T.nranks;
+        // order matters when both neighbours are the same peer (2 ranks) or the rank itself (1 rank):
+        // [send up, send down] pairs with the peer's [recv from below, recv from above]
+        r = T.nc->Send(b[1], cnt, ncclDouble, up, T.comm[i], T.cs[i]);
+        if (r == ncclSuccess) r = T.nc->Send(b[0], cnt, ncclDouble, dn, T.comm[i], T.cs[i]);
+        if (r == ncclSuccess) r = T.nc->Recv(b[2], cnt, ncclDouble, dn, T.comm[i], T.cs[i]);
+        if (r == ncclSuccess) r = T.nc->Recv(b[3], cnt, ncclDouble, up, T.comm[i], T.cs[i]);
+      }
+      if (r != ncclSuccess) {
+        (void)T.nc->GroupEnd();
+        T.err = std::string("RCCL exchange failed: ") + T.nc->GetErrorString(r);
+        return EKPNP_ERR_HIP;
+      }
+    }
+    TNCCL(T, T.nc->GroupEnd());
+  } else {
+    for (int i = 0; i < n; ++i) {
+      Ctx& c = S(T, i);
+      if ((rc = use(T, i))) return rc;
+      if (x == X_EDGE) {
+        const size_t per = 4 * (size_t)c.p.ny * c.nxh;
+        for (int j = 0; j < n; ++j) THIP(T, xcopy(S(T, j).edge_all + (size_t)c.rank * per, S(T, j).device, c.edge_local, c.device, per * sizeof(double), T.cs[i]));
+      } else {
+        const int up = (i + 1) % n, dn = (i + n - 1) % n;
+        Ctx &cu = S(T, up), &cd = S(T, dn);
+        double **b = x == X_HALO ? c.halo : c.phi_halo, **bu = x == X_HALO ? cu.halo : cu.phi_halo, **bd = x == X_HALO ? cd.halo : cd.phi_halo;
+        const size_t bytes = (x == X_HALO ? c.halo_doubles : c.plane) * sizeof(double);
+        THIP(T, xcopy(bu[2], cu.device, b[1], c.device, bytes, T.cs[i]));  // my send-up   -> upper neighbour's recv-from-below
+        THIP(T, xcopy(bd[3], cd.device, b[0], c.device, bytes, T.cs[i]));  // my send-down -> lower neighbour's recv-from-above
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    THIP(T, hipEventRecord(T.done[x][i], T.cs[i]));
+  }
+  return EKPNP_OK;
+}
+
+// what the slabs enqueue on their compute streams from here on sees the exchanged data
+static int exchange_finish(Team& T, int x) {
+  const int n = (int)T.m.size();
+  int rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    THIP(T, hipStreamWaitEvent(S(T, i).stream, T.done[x][i], 0));
+    if (T.kind == EKPNP_TRANSPORT_COPY) {
+      hipError_t e = hipSuccess;
+      for_partners(T, i, x, [&](int j) { if (e == hipSuccess) e = hipStreamWaitEvent(S(T, i).stream, T.done[x][j], 0); });
+      THIP(T, e);
+    }
+  }
+  return EKPNP_OK;
+}
+
+// stream_collide_save (LBM.cu:465-481) over the slabs, halo exchange hidden behind the interior planes
+static int team_stream_collide_save(Team& T) {
+  const int n = (int)T.m.size();
+  int rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    TSLAB(T, i, ekpnp_collide_boundary_planes(T.m[i]));
+    TSLAB(T, i, ekpnp_halo_pack(T.m[i]));
+  }
+  if ((rc = exchange_begin(T, X_HALO))) return rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    TSLAB(T, i, ekpnp_collide_interior_planes(T.m[i]));
+  }
+  if ((rc = exchange_finish(T, X_HALO))) return rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    TSLAB(T, i, ekpnp_halo_unpack(T.m[i]));
+  }
+  return EKPNP_OK;
+}
+
+// fast_Poisson (poisson.cu:75-103) over the slabs
+static int team_fast_poisson(Team& T) {
+  const int n = (int)T.m.size();
+  int rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    TSLAB(T, i, ekpnp_poisson_stage1(T.m[i]));
+  }
+  if ((rc = exchange_begin(T, X_EDGE)) || (rc = exchange_finish(T, X_EDGE))) return rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    TSLAB(T, i, ekpnp_poisson_stage2(T.m[i]));
+    TSLAB(T, i, ekpnp_phi_halo_pack(T.m[i]));
+  }
+  if ((rc = exchange_begin(T, X_PHI)) || (rc = exchange_finish(T, X_PHI))) return rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    TSLAB(T, i, ekpnp_poisson_stage3(T.m[i]));
+  }
+  return EKPNP_OK;
+}
+
+static int team_step(Team& T, int nsteps) {  // main.cu:189-200
+  if (nsteps < 0) { T.err = "nsteps < 0"; return EKPNP_ERR_INVALID; }
+  for (int s = 0; s < nsteps; ++s) {
+    int rc = team_stream_collide_save(T);
+    if (rc == EKPNP_OK) rc = team_fast_poisson(T);
+    if (rc) return rc;
+    for (size_t i = 0; i < T.m.size(); ++i) TSLAB(T, (int)i, ekpnp_advance_time(T.m[i]));
+  }
+  return EKPNP_OK;
+}
+
+static int team_synchronize(Team& T) {
+  int rc;
+  for (size_t i = 0; i < T.m.size(); ++i) {
+    if ((rc = use(T, (int)i))) return rc;
+    THIP(T, hipStreamSynchronize(T.cs[i]));
+    TSLAB(T, (int)i, ekpnp_synchronize(T.m[i]));
+  }
+  return EKPNP_OK;
+}
+
+// combine one number per local slab over all ranks: sum or max.  Every rank gets the result.
+static int team_reduce(Team& T, const std::vector<double>& local, bool is_max, double* out) {
+  double v = local.empty() ? 0.0 : local[0];
+  for (size_t i = 1; i < local.size(); ++i) v = is_max ? std::fmax(v, local[i]) : v + local[i];
+  if (!T.all_local) {  // one local slab, the others are other processes
+    int rc = use(T, 0);
+    if (rc) return rc;
+    hipStream_t st = S(T, 0).stream;
+    THIP(T, hipMemcpyAsync(T.red[0], &v, sizeof(double), hipMemcpyHostToDevice, st));
+    TNCCL(T, T.nc->AllReduce(T.red[0], T.red[0] + 1, 1, ncclDouble, is_max ? ncclMax : ncclSum, T.comm[0], st));
+    THIP(T, hipMemcpyAsync(&v, T.red[0] + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+    THIP(T, hipStreamSynchronize(st));
+  }
+  *out = v;
+  return EKPNP_OK;
+}
+
+// initialization() (LBM.cu:68-109) with the slab Poisson solve inside the Picard loop
+static int team_initialization(Team& T) {
+  const int n = (int)T.m.size();
+  int rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    TSLAB(T, i, ekpnp_init_fields(T.m[i]));  // gpu_initialization, LBM.cu:76
+    TSLAB(T, i, ekpnp_pbe_begin(T.m[i]));    // LBM.cu:79-86
+  }
+  const int sweeps = S(T, 0).p.pb_iterations;
+  for (int it = 0; it < sweeps; ++it) {      // LBM.cu:89-106
+    for (int i = 0; i < n; ++i) {
+      if ((rc = use(T, i))) return rc;
+      TSLAB(T, i, ekpnp_pbe_concentrations(T.m[i]));
+    }
+    if ((rc = team_fast_poisson(T))) return rc;
+    for (int i = 0; i < n; ++i) {
+      if ((rc = use(T, i))) return rc;
+      TSLAB(T, i, ekpnp_pbe_relax(T.m[i]));
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    if ((rc = use(T, i))) return rc;
+    TSLAB(T, i, ekpnp_pbe_end(T.m[i]));
+  }
+  return EKPNP_OK;
+}
+
+// ekpnp_initialization_converged over the slabs: same damping rule, residual = max over all ranks
+static int team_initialization_converged(Team& T, double rel_tol, int max_sweeps, int* sweeps, double* residual) {
+  if (max_sweeps < 0) { T.err = "max_sweeps < 0"; return EKPNP_ERR_INVALID; }
+  const int n = (int)T.m.size();
+  const ekpnp_params& p = S(T, 0).p;
+  double omega = p.PB_omega;
+  if (p.chargeinf > 0.0) {
+    const double lam2 = p.eps * p.kB * p.roomT / p.electron / (2.0 * p.chargeinf * p.convertCtoCharge);
+    const double A = p.Lz * p.Lz / (M_PI * M_PI * lam2);
+    if (1.6 / (1.0 + A) < omega) omega = 1.6 / (1.0 + A);
+  }
+  double scale = std::fabs(p.voltage) > std::fabs(p.voltage2) ? std::fabs(p.voltage) : std::fabs(p.voltage2);
+  if (scale == 0.0) scale = 1.0;
+  int rc;
+  for (int i = 0; i < n; ++i) {
+    Ctx& c = S(T, i);
+    if ((rc = use(T, i))) return rc;
+    if (!c.diag) THIP(T, hipMalloc((void**)&c.diag, DIAG_SCRATCH * sizeof(double)));
+    TSLAB(T, i, ekpnp_init_fields(T.m[i]));
+    TSLAB(T, i, ekpnp_pbe_begin(T.m[i]));
+  }
+  int done = 0;
+  double res = 0.0;
+  const int check_every = 10;
+  rc = EKPNP_OK;
+  while (done < max_sweeps) {
+    for (int i = 0; i < n; ++i) {
+      if ((rc = use(T, i))) return rc;
+      TSLAB(T, i, ekpnp_pbe_concentrations(T.m[i]));
+    }
+    if ((rc = team_fast_poisson(T))) break;
+    ++done;
+    const bool check = (done % check_every == 0) || done == max_sweeps;
+    for (int i = 0; i < n; ++i) {
+      Ctx& c = S(T, i);
+      if ((rc = use(T, i))) return rc;
+      if (check) launch_max_abs_diff(c, c.fld[EKPNP_PHI], c.phi_old, c.diag);
+      launch_pbe_relax(c, c.phi_old, omega);
+    }
+    if (check) {
+      std::vector<double> r(n, 0.0);
+      for (int i = 0; i < n; ++i) {
+        Ctx& c = S(T, i);
+        if ((rc = use(T, i))) return rc;
+        THIP(T, hipMemcpyAsync(&r[i], c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        THIP(T, hipStreamSynchronize(c.stream));
+        if (!(r[i] == r[i])) r[i] = 1.0e300;  // NaN must win the max
+      }
+      double rmax = 0.0;
+      if ((rc = team_reduce(T, r, true, &rmax))) break;
+      res = rmax / scale;
+      if (rmax >= 1.0e300) { T.err = "Poisson-Boltzmann iteration produced NaN"; rc = EKPNP_ERR_INVALID; break; }
+      if (res <= rel_tol) break;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    if (use(T, i) == EKPNP_OK) (void)ekpnp_pbe_end(T.m[i]);
+  }
+  if (sweeps) *sweeps = done;
+  if (residual) *residual = res;
+  return rc;
+}
+
+// fn on every slab of the lattice in rank order (whole-lattice text files are written plane by
+// plane); between the turns of different processes the ranks agree on the status so far
+static int team_turns(Team& T, int (*fn)(Ctx&, void*), void* arg) {
+  int status = EKPNP_OK;
+  for (int r = 0; r < T.nranks; ++r) {
+    const int slot = T.all_local ? r : (S(T, 0).rank == r ? 0 : -1);
+    if (slot >= 0 && status == EKPNP_OK) {
+      int rc = use(T, slot);
+      if (rc == EKPNP_OK) {
+        rc = fn(S(T, slot), arg);
+        if (rc) T.err = "slab " + std::to_string(r) + ": " + S(T, slot).err;
+      }
+      status = rc;
+    }
+    if (!T.all_local) {
+      double worst = 0.0;
+      int rc = team_reduce(T, {(double)status}, true, &worst);
+      if (rc) return rc;
+      if (worst != 0.0 && status == EKPNP_OK) {
+        T.err = "file IO failed on another rank";
+        status = (int)worst;
+      }
+    }
+  }
+  return status;
+}
+
+// ---- resources -----------------------------------------------------------------------------------
+static int team_make_streams(Team& T) {
+  const int n = (int)T.m.size();
+  T.cs.assign(n, nullptr);
+  T.red.assign(n, nullptr);
+  for (int x = 0; x < X_KINDS; ++x) { T.ready[x].assign(n, nullptr); T.done[x].assign(n, nullptr); }
+  for (int i = 0; i < n; ++i) {
+    int rc = use(T, i);
+    if (rc) return rc;
+    int least = 0, greatest = 0;
+    THIP(T, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // highest priority: a transfer enqueued behind tens of milliseconds of collision kernels must be
+    // dispatched as soon as workgroup slots free up, not after the compute queue has drained
+    THIP(T, hipStreamCreateWithPriority(&T.cs[i], hipStreamNonBlocking, greatest));
+    for (int x = 0; x < X_KINDS; ++x) {
+      THIP(T, hipEventCreateWithFlags(&T.ready[x][i], hipEventDisableTiming));
+      THIP(T, hipEventCreateWithFlags(&T.done[x][i], hipEventDisableTiming));
+    }
+    THIP(T, hipMalloc((void**)&T.red[i], 2 * sizeof(double)));
+  }
+  return EKPNP_OK;
+}
+
+static void team_release(Team& T) {
+  for (size_t i = 0; i < T.m.size(); ++i) {
+    (void)hipSetDevice(S(T, (int)i).device);
+    if (i < T.cs.size() && T.cs[i]) (void)hipStreamSynchronize(T.cs[i]);
+    if (S(T, (int)i).stream) (void)hipStreamSynchronize(S(T, (int)i).stream);
+  }
+  for (size_t i = 0; i < T.comm.size(); ++i)
+    if (T.comm[i] && T.nc) (void)T.nc->CommDestroy(T.comm[i]);
+  T.comm.clear();
+  for (size_t i = 0; i < T.m.size(); ++i) {
+    (void)hipSetDevice(S(T, (int)i).device);
+    for (int x = 0; x < X_KINDS; ++x) {
+      if (i < T.ready[x].size() && T.ready[x][i]) (void)hipEventDestroy(T.ready[x][i]);
+      if (i < T.done[x].size() && T.done[x][i]) (void)hipEventDestroy(T.done[x][i]);
+    }
+    if (i < T.cs.size() && T.cs[i]) (void)hipStreamDestroy(T.cs[i]);
+    if (i < T.red.size() && T.red[i]) (void)hipFree(T.red[i]);
+  }
+  T.cs.clear();
+  T.red.clear();
+  for (int x = 0; x < X_KINDS; ++x) { T.ready[x].clear(); T.done[x].clear(); }
+}
+
+// ---- the reference's verbs on ONE attached slab context (one process per GPU) --------------------
+static int own_team(Ctx& c, Team** T) {
+  if (!c.team) { c.err = "slab context without a transport: ekpnp_slab_attach_comm it, use ekpnp_group_*, or drive the split calls"; return EKPNP_ERR_INVALID; }
+  if (c.team->group) { c.err = "this slab belongs to an ekpnp_group: use the ekpnp_group_* calls"; return EKPNP_ERR_INVALID; }
+  *T = c.team;
+  return EKPNP_OK;
+}
+#define OWN_TEAM(c)                  \
+  Team* T = nullptr;                 \
+  {                                  \
+    int rc0_ = own_team(c, &T);      \
+    if (rc0_) return rc0_;           \
+  }
+static int lift(Ctx& c, Team& T, int rc) {
+  if (rc && c.err.empty()) c.err = T.err;
+  else if (rc) c.err = T.err.empty() ? c.err : T.err;
+  return rc;
+}
+
+int team_ctx_stream_collide_save(Ctx& c) { OWN_TEAM(c); return lift(c, *T, team_stream_collide_save(*T)); }
+int team_ctx_fast_poisson(Ctx& c) { OWN_TEAM(c); return lift(c, *T, team_fast_poisson(*T)); }
+int team_ctx_step(Ctx& c, int n) { OWN_TEAM(c); return lift(c, *T, team_step(*T, n)); }
+int team_ctx_initialization(Ctx& c) { OWN_TEAM(c); return lift(c, *T, team_initialization(*T)); }
+int team_ctx_initialization_converged(Ctx& c, double tol, int maxs, int* sweeps, double* res) {
+  OWN_TEAM(c);
+  return lift(c, *T, team_initialization_converged(*T, tol, maxs, sweeps, res));
+}
+int team_ctx_reduce(Ctx& c, double* value, bool is_max) {
+  OWN_TEAM(c);
+  double out = 0.0;
+  int rc = team_reduce(*T, {*value}, is_max, &out);
+  if (rc == EKPNP_OK) *value = out;
+  return lift(c, *T, rc);
+}
+int team_ctx_turns(Ctx& c, int (*fn)(Ctx&, void*), void* arg) { OWN_TEAM(c); return lift(c, *T, team_turns(*T, fn, arg)); }
+
+void team_detach(Ctx& c) {
+  if (!c.team || c.team->group) return;  // a group releases its own team (ekpnp_group_destroy)
+  Team* T = c.team;
+  team_release(*T);
+  c.team = nullptr;
+  delete T;
+}
+
+}  // namespace ekpnp
+
+using namespace ekpnp;
+
+// ---- C ABI: one process per GPU --------------------------------------------------------------------
+
+extern "C" int ekpnp_comm_unique_id(void* id128) {
+  if (!id128) return EKPNP_ERR_INVALID;
+  std::string err;
+  Rccl* nc = rccl(err);
+  if (!nc) return EKPNP_ERR_HIP;
+  ncclUniqueId id;
+  if (nc->GetUniqueId(&id) != ncclSuccess) return EKPNP_ERR_HIP;
+  static_assert(sizeof(id) == EKPNP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id128, &id, sizeof id);
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
+  if (!ctx) return EKPNP_ERR_INVALID;
+  Ctx& c = ctx->c;
+  if (!c.slab) { c.err = "ekpnp_slab_attach_comm needs a context made by ekpnp_create_slab"; return EKPNP_ERR_INVALID; }
+  if (c.team) { c.err = "this slab already has a transport"; return EKPNP_ERR_INVALID; }
+  if (!id128) { c.err = "NULL id"; return EKPNP_ERR_INVALID; }
+  Rccl* nc = rccl(c.err);
+  if (!nc) return EKPNP_ERR_HIP;
+  Team* T = new (std::nothrow) Team();
+  if (!T) { c.err = "host allocation failed"; return EKPNP_ERR_NOMEM; }
+  T->m = {ctx};
+  T->nranks = c.nranks;
+  T->all_local = c.nranks == 1;
+  T->group = false;
+  T->kind = EKPNP_TRANSPORT_RCCL;
+  T->nc = nc;
+  int rc = team_make_streams(*T);
+  if (rc == EKPNP_OK) {
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    T->comm.assign(1, nullptr);
+    ncclResult_t r = nc->CommInitRank(&T->comm[0], c.nranks, id, c.rank);  // collective over the ranks
+    if (r != ncclSuccess) { T->err = std::string("ncclCommInitRank: ") + nc->GetErrorString(r); T->comm.clear(); rc = EKPNP_ERR_HIP; }
+  }
+  if (rc) {
+    c.err = T->err;
+    team_release(*T);
+    delete T;
+    return rc;
+  }
+  c.team = T;
+  c.team_slot = 0;
+  return EKPNP_OK;
+}
+
+// ---- C ABI: one process, N slabs (ekpnp_main --gpus N) -------------------------------------------
+
+struct ekpnp_group {
+  Team t;
+};
+
+static thread_local std::string g_group_err;
+
+extern "C" const char* ekpnp_group_last_error(const ekpnp_group* g) { return g ? g->t.err.c_str() : g_group_err.c_str(); }
+
+extern "C" int ekpnp_group_destroy(ekpnp_group* g) {
+  if (!g) return EKPNP_ERR_INVALID;
+  Team& T = g->t;
+  team_release(T);
+  for (ekpnp_ctx* m : T.m) {
+    (void)hipSetDevice(m->c.device);
+    m->c.team = nullptr;
+    (void)ekpnp_destroy(m);
+  }
+  delete g;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_group_create(const ekpnp_params* p, int nslabs, const int* devices, int transport, ekpnp_group** out) {
+  if (!out) { g_group_err = "out is NULL"; return EKPNP_ERR_INVALID; }
+  *out = nullptr;
+  if (!p || nslabs < 1 || nslabs > 16) { g_group_err = "ekpnp_group_create: 1 to 16 slabs"; return EKPNP_ERR_INVALID; }
+  if (transport != EKPNP_TRANSPORT_AUTO && transport != EKPNP_TRANSPORT_RCCL && transport != EKPNP_TRANSPORT_COPY) {
+    g_group_err = "ekpnp_group_create: unknown transport";
+    return EKPNP_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_group_err = "no HIP device"; return EKPNP_ERR_HIP; }
+  std::vector<int> dev(nslabs);
+  bool distinct = true;
+  for (int i = 0; i < nslabs; ++i) {
+    dev[i] = devices ? devices[i] : i % ndev;
+    if (dev[i] < 0 || dev[i] >= ndev) { g_group_err = "ekpnp_group_create: device index out of range"; return EKPNP_ERR_INVALID; }
+    for (int j = 0; j < i; ++j) distinct = distinct && dev[j] != dev[i];
+  }
+  // RCCL refuses two ranks on one device: slabs that share a device move their halos by copies
+  int kind = transport;
+  if (kind == EKPNP_TRANSPORT_AUTO) kind = (distinct && nslabs > 1) ? EKPNP_TRANSPORT_RCCL : EKPNP_TRANSPORT_COPY;
+  if (kind == EKPNP_TRANSPORT_RCCL && !distinct) {
+    g_group_err = "EKPNP_TRANSPORT_RCCL needs one device per slab (RCCL refuses two ranks on one device): use EKPNP_TRANSPORT_COPY";
+    return EKPNP_ERR_INVALID;
+  }
+  ekpnp_group* g = new (std::nothrow) ekpnp_group();
+  if (!g) { g_group_err = "host allocation failed"; return EKPNP_ERR_NOMEM; }
+  Team& T = g->t;
+  T.nranks = nslabs;
+  T.all_local = true;
+  T.group = true;
+  T.kind = kind;
+  auto bail = [&](int code) {
+    g_group_err = T.err;
+    ekpnp_group_destroy(g);
+    return code;
+  };
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  for (int i = 0; i < nslabs; ++i) {
+    if (hipSetDevice(dev[i]) != hipSuccess) { T.err = "hipSetDevice failed"; return bail(EKPNP_ERR_HIP); }
+    ekpnp_ctx* c = nullptr;
+    int rc = ekpnp_create_slab(p, i, nslabs, &c);
+    if (rc) { T.err = std::string("slab ") + std::to_string(i) + ": " + ekpnp_last_error(nullptr); return bail(rc); }
+    c->c.team = &T;
+    c->c.team_slot = i;
+    T.m.push_back(c);
+  }
+  int rc = team_make_streams(T);
+  if (rc) return bail(rc);
+  if (kind == EKPNP_TRANSPORT_RCCL) {
+    T.nc = rccl(T.err);
+    if (!T.nc) return bail(EKPNP_ERR_HIP);
+    T.comm.assign(nslabs, nullptr);
+    ncclResult_t r = T.nc->CommInitAll(T.comm.data(), nslabs, dev.data());
+    if (r != ncclSuccess) { T.err = std::string("ncclCommInitAll: ") + T.nc->GetErrorString(r); T.comm.clear(); return bail(EKPNP_ERR_HIP); }
+  } else if (distinct && nslabs > 1) {
+    // direct peer copies over xGMI where the devices allow it (otherwise HIP stages through the host)
+    for (int i = 0; i < nslabs; ++i)
+      for (int j = 0; j < nslabs; ++j) {
+        int can = 0;
+        if (i != j && hipDeviceCanAccessPeer(&can, dev[i], dev[j]) == hipSuccess && can) {
+          (void)hipSetDevice(dev[i]);
+          hipError_t e = hipDeviceEnablePeerAccess(dev[j], 0);
+          if (e != hipSuccess) (void)hipGetLastError();  // already enabled is fine
+        }
+      }
+  }
+  (void)hipSetDevice(prev);
+  *out = g;
+  return EKPNP_OK;
+}
+
+#define NEEDGROUP(g)                    \
+  if (!(g)) return EKPNP_ERR_INVALID;   \
+  Team& T = (g)->t
+
+extern "C" int ekpnp_group_size(const ekpnp_group* g) { return g ? (int)g->t.m.size() : 0; }
+extern "C" int ekpnp_group_transport(const ekpnp_group* g) { return g ? g->t.kind : 0; }
+
+extern "C" int ekpnp_group_context(ekpnp_group* g, int slab, ekpnp_ctx** ctx) {
+  NEEDGROUP(g);
+  if (!ctx || slab < 0 || slab >= (int)T.m.size()) { T.err = "bad slab index"; return EKPNP_ERR_INVALID; }
+  *ctx = T.m[slab];
+  return EKPNP_OK;
+}
+
+extern "C" size_t ekpnp_group_device_bytes(const ekpnp_group* g) {
+  size_t b = 0;
+  if (g) for (ekpnp_ctx* m : g->t.m) b += ekpnp_device_bytes(m);
+  return b;
+}
+
+extern "C" int ekpnp_group_synchronize(ekpnp_group* g) { NEEDGROUP(g); return team_synchronize(T); }
+extern "C" int ekpnp_group_initialization(ekpnp_group* g) { NEEDGROUP(g); return team_initialization(T); }
+extern "C" int ekpnp_group_initialization_converged(ekpnp_group* g, double rel_tol, int max_sweeps, int* sweeps, double* residual) {
+  NEEDGROUP(g);
+  return team_initialization_converged(T, rel_tol, max_sweeps, sweeps, residual);
+}
+extern "C" int ekpnp_group_init_equilibrium(ekpnp_group* g) {
+  NEEDGROUP(g);
+  for (size_t i = 0; i < T.m.size(); ++i) {
+    int rc = use(T, (int)i);
+    if (rc) return rc;
+    TSLAB(T, (int)i, ekpnp_init_equilibrium(T.m[i]));
+  }
+  return EKPNP_OK;
+}
+extern "C" int ekpnp_group_stream_collide_save(ekpnp_group* g, double t) { NEEDGROUP(g); (void)t; return team_stream_collide_save(T); }
+extern "C" int ekpnp_group_fast_poisson(ekpnp_group* g) { NEEDGROUP(g); return team_fast_poisson(T); }
+extern "C" int ekpnp_group_step(ekpnp_group* g, int nsteps) { NEEDGROUP(g); return team_step(T, nsteps); }
+
+extern "C" int ekpnp_group_get_time(ekpnp_group* g, double* t) {
+  NEEDGROUP(g);
+  if (!t) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
+  return ekpnp_get_time(T.m[0], t);
+}
+extern "C" int ekpnp_group_set_time(ekpnp_group* g, double t) {
+  NEEDGROUP(g);
+  for (ekpnp_ctx* m : T.m) (void)ekpnp_set_time(m, t);
+  return EKPNP_OK;
+}
+
+// whole-lattice host arrays [NZ][NY][NX] <-> the slabs' planes
+extern "C" int ekpnp_group_set_field(ekpnp_group* g, int field_id, const double* host) {
+  NEEDGROUP(g);
+  if (!host) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
+  for (size_t i = 0; i < T.m.size(); ++i) {
+    int rc = use(T, (int)i);
+    if (rc) return rc;
+    TSLAB(T, (int)i, ekpnp_set_field(T.m[i], field_id, host + (size_t)S(T, (int)i).z0 * S(T, (int)i).plane));
+  }
+  return EKPNP_OK;
+}
+extern "C" int ekpnp_group_get_field(ekpnp_group* g, int field_id, double* host) {
+  NEEDGROUP(g);
+  if (!host) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
+  for (size_t i = 0; i < T.m.size(); ++i) {
+    int rc = use(T, (int)i);
+    if (rc) return rc;
+    THIP(T, hipStreamSynchronize(T.cs[i]));
+    TSLAB(T, (int)i, ekpnp_get_field(T.m[i], field_id, host + (size_t)S(T, (int)i).z0 * S(T, (int)i).plane));
+  }
+  return EKPNP_OK;
+}
+
+// diagnostics (main.cu:211-222): every slab reduces its own planes on its device, the host combines
+static int group_diag(Team& T, bool is_max, double* out) {
+  std::vector<double> v(T.m.size(), 0.0);
+  for (size_t i = 0; i < T.m.size(); ++i) {
+    int rc = use(T, (int)i);
+    if (rc) return rc;
+    ekpnp_ctx* m = T.m[i];
+    Team* keep = m->c.team;
+    m->c.team = nullptr;  // the slab's own value, not a team reduction
+    rc = is_max ? ekpnp_umax(m, &v[i]) : ekpnp_current(m, &v[i]);
+    m->c.team = keep;
+    if (rc) { T.err = "slab " + std::to_string(i) + ": " + m->c.err; return rc; }
+  }
+  return team_reduce(T, v, is_max, out);
+}
+extern "C" int ekpnp_group_current(ekpnp_group* g, double* I) {
+  NEEDGROUP(g);
+  if (!I) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
+  return group_diag(T, false, I);
+}
+extern "C" int ekpnp_group_umax(ekpnp_group* g, double* umax) {
+  NEEDGROUP(g);
+  if (!umax) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
+  return group_diag(T, true, umax);
+}
+extern "C" int ekpnp_group_record_umax(ekpnp_group* g, const char* path, int append, double time) {
+  NEEDGROUP(g);
+  if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
+  double um = 0.0;
+  int rc = group_diag(T, true, &um);
+  if (rc) return rc;
+  FILE* f = std::fopen(path, append ? "ab" : "wb");
+  if (!f) { T.err = "cannot open umax file"; return EKPNP_ERR_INVALID; }
+  std::fprintf(f, "%10.6f %10.6f\n", time, um);  // LBM.cu:2748
+  std::fclose(f);
+  return EKPNP_OK;
+}
+
+// whole-lattice text files: every slab appends its planes in rank order
+static int write_part(Ctx& c, void* arg) {
+  TextIoArgs a = *static_cast<TextIoArgs*>(arg);
+  if (c.rank != 0) a.append = 1;
+  return io_write_text_part(c, a);
+}
+extern "C" int ekpnp_group_save_data_tecplot(ekpnp_group* g, const char* path, int append, double time, int first) {
+  NEEDGROUP(g);
+  if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
+  TextIoArgs a{path, append, time, first, 0};
+  return team_turns(T, write_part, &a);
+}
+extern "C" int ekpnp_group_save_data_end(ekpnp_group* g, const char* path, int append, double time) {
+  NEEDGROUP(g);
+  if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
+  TextIoArgs a{path, append, time, 0, 1};
+  return team_turns(T, write_part, &a);
+}
+namespace {
+struct ReadArgs { const char* path; double* time; };
+int read_part(Ctx& c, void* arg) {
+  ReadArgs* a = static_cast<ReadArgs*>(arg);
+  return io_read_data_part(c, a->path, a->time);
+}
+}  // namespace
+extern "C" int ekpnp_group_read_data(ekpnp_group* g, const char* path, double* time) {
+  NEEDGROUP(g);
+  if (!path || !time) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
+  ReadArgs a{path, time};
+  return team_turns(T, read_part, &a);
+}
+
+// whole-lattice EKPNPST1 file (same format a single context writes: z0 = 0, nz_local = nz)
+namespace {
+struct StateHeader {
+  char magic[8];
+  int32_t nx, ny, nz, z0, nzl, nfields;
+  double time;
+};
+static_assert(sizeof(StateHeader) == 40, "state header layout");
+constexpr size_t STATE_CHUNK = (size_t)4 << 20;
+}  // namespace
+
+extern "C" int ekpnp_group_save_state(ekpnp_group* g, const char* path, double time) {
+  NEEDGROUP(g);
+  if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
+  int rc = team_synchronize(T);
+  if (rc) return rc;
+  FILE* f = std::fopen(path, "wb");
+  if (!f) { T.err = "cannot open state file"; return EKPNP_ERR_INVALID; }
+  const ekpnp_params& p = S(T, 0).p;
+  StateHeader h{};
+  std::memcpy(h.magic, "EKPNPST1", 8);
+  h.nx = p.nx; h.ny = p.ny; h.nz = p.nz; h.z0 = 0; h.nzl = p.nz; h.nfields = EKPNP_NFIELDS;
+  h.time = time;
+  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+  std::vector<double> buf(STATE_CHUNK);
+  hipError_t e = hipSuccess;
+  for (int id = 0; ok && e == hipSuccess && id < EKPNP_NFIELDS; ++id)
+    for (size_t i = 0; ok && e == hipSuccess && i < T.m.size(); ++i) {
+      Ctx& c = S(T, (int)i);
+      e = hipSetDevice(c.device);
+      for (size_t o = 0; ok && e == hipSuccess && o < c.nloc; o += buf.size()) {
+        const size_t n = c.nloc - o < buf.size() ? c.nloc - o : buf.size();
+        e = hipMemcpy(buf.data(), c.fld[id] + o, n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) ok = std::fwrite(buf.data(), sizeof(double), n, f) == n;
+      }
+    }
+  ok = (std::fclose(f) == 0) && ok;
+  THIP(T, e);
+  if (!ok) { T.err = "write error on state file"; return EKPNP_ERR_INVALID; }
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_group_read_state(ekpnp_group* g, const char* path, double* time) {
+  NEEDGROUP(g);
+  if (!path || !time) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
+  int rc = team_synchronize(T);
+  if (rc) return rc;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { T.err = "cannot open state file"; return EKPNP_ERR_INVALID; }
+  const ekpnp_params& p = S(T, 0).p;
+  StateHeader h{};
+  if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "EKPNPST1", 8) != 0) {
+    std::fclose(f);
+    T.err = "not an EKPNPST1 state file";
+    return EKPNP_ERR_INVALID;
+  }
+  if (h.nx != p.nx || h.ny != p.ny || h.nz != p.nz || h.z0 != 0 || h.nzl != p.nz || h.nfields != EKPNP_NFIELDS) {
+    std::fclose(f);
+    T.err = "state file does not hold this whole lattice";
+    return EKPNP_ERR_INVALID;
+  }
+  std::vector<double> buf(STATE_CHUNK);
+  bool ok = true;
+  hipError_t e = hipSuccess;
+  for (int id = 0; ok && e == hipSuccess && id < EKPNP_NFIELDS; ++id)
+    for (size_t i = 0; ok && e == hipSuccess && i < T.m.size(); ++i) {
+      Ctx& c = S(T, (int)i);
+      e = hipSetDevice(c.device);
+      for (size_t o = 0; ok && e == hipSuccess && o < c.nloc; o += buf.size()) {
+        const size_t n = c.nloc - o < buf.size() ? c.nloc - o : buf.size();
+        ok = std::fread(buf.data(), sizeof(double), n, f) == n;
+        if (ok) e = hipMemcpy(c.fld[id] + o, buf.data(), n * sizeof(double), hipMemcpyHostToDevice);
+      }
+      c.rhs_ready = false;
+      c.t = h.time;
+    }
+  std::fclose(f);
+  THIP(T, e);
+  if (!ok) { T.err = "state file is shorter than the lattice"; return EKPNP_ERR_INVALID; }
+  *time = h.time;
+  return EKPNP_OK;
+}

@@ -101,6 +101,7 @@ typedef struct oracle_state {
   /* populations, reference layout: X0[NZ][NY][NX], X1/X2[26][NZ][NY][NX] (LBM.cu:17-30) */
   double *x0[4], *x1[4], *x2[4];
   double* f0bc; /* [2][NY][NX], main.cu:78 */
+  double* u0_alt; /* [8][3][NY][NX]: the z==0 velocity under every resolution of the reference's race */
   double* fld[EKPNP_NFIELDS];
   double* phi_old;
   cplx *ext_a, *ext_b; /* odd-extension work arrays, [NE][NY][NX] */
@@ -162,6 +163,7 @@ oracle_state* oracle_create(const ekpnp_params* p, int dc_mode) {
     s->x2[l] = (double*)calloc(s->n * 26, sizeof(double));
   }
   s->f0bc = (double*)calloc((size_t)2 * p->nx * p->ny, sizeof(double));
+  s->u0_alt = (double*)calloc((size_t)8 * 3 * p->nx * p->ny, sizeof(double));
   for (int i = 0; i < EKPNP_NFIELDS; ++i) s->fld[i] = (double*)calloc(s->n, sizeof(double));
   s->phi_old = (double*)calloc(s->n, sizeof(double));
   size_t next = (size_t)p->nx * p->ny * s->ne;
@@ -189,6 +191,7 @@ void oracle_destroy(oracle_state* s) {
   if (!s) return;
   for (int l = 0; l < 4; ++l) { free(s->x0[l]); free(s->x1[l]); free(s->x2[l]); }
   free(s->f0bc);
+  free(s->u0_alt);
   for (int i = 0; i < EKPNP_NFIELDS; ++i) free(s->fld[i]);
   free(s->phi_old); free(s->ext_a); free(s->ext_b); free(s->kx); free(s->ky); free(s->kz);
   free(s);
@@ -481,8 +484,40 @@ void oracle_collide_save(oracle_state* s) {
           for (int d = 1; d < Q; ++d) s->x2[l][nidx(s, x, y, z, d)] = out[l][d];
         }
       }
+  /* The reference's z==0 thread reads the rest populations of node z=1 (LBM.cu:664-667) which
+   * the z=1 thread overwrites in place in the same launch (LBM.cu:1711-1714): a read-after-write
+   * race.  The fields above hold the canonical resolution (pre-collision values, what a z-ascending
+   * execution sees).  u0_alt[mask] holds the same formula with node z=1's POST-collision rest
+   * population of h (mask bit 0), hn (bit 1) and temp (bit 2) - the three that enter the velocity
+   * through the force (f0 does not carry momentum) - so that a test can accept, node by node, any
+   * outcome of the race in outputs of the reference's own kernels.  mask 0 repeats the canonical one. */
+  for (int mask = 0; mask < 8; ++mask)
+    for (int y = 0; y < NY; ++y)
+      for (int x = 0; x < NX; ++x) {
+        double fm_[4][Q];
+        for (int l = 0; l < 4; ++l) {
+          const int post = l >= 1 && ((mask >> (l - 1)) & 1);
+          fm_[l][0] = post ? s->x0[l][sidx(s, x, y, 1)] : rest1[l][sidx(s, x, y, 0)];
+          for (int d = 1; d < Q; ++d) fm_[l][d] = s->x1[l][nidx(s, x, y, 1, d)];
+        }
+        const double rhoinvm = 1.0 / s->fld[EKPNP_RHO][sidx(s, x, y, 0)];
+        const double chargem = sum27(fm_[1]), chargenm = sum27(fm_[2]), tempm = sum27(fm_[3]);
+        const size_t i1 = sidx(s, x, y, 1);
+        const double Exm = s->fld[EKPNP_EX][i1], Eym = s->fld[EKPNP_EY][i1], Ezm = s->fld[EKPNP_EZ][i1];
+        const double forcexm = F * (chargem - chargenm) * (Exm + p->Ext) + p->exf;
+        const double forceym = F * (chargem - chargenm) * Eym;
+        const double forcezm = F * (chargem - chargenm) * Ezm + p->rho0 * tempm * p->Ra * p->nu * p->D;
+        double* out = s->u0_alt + (size_t)mask * 3 * plane + (size_t)y * NX + x;
+        out[0] = -rhoinvm * ((sum9(fm_[0], MX_P) - (sum9(fm_[0], MX_M))) / CFL + forcexm * dt * 0.5);
+        out[plane] = -rhoinvm * ((sum9(fm_[0], MY_P) - (sum9(fm_[0], MY_M))) / CFL + forceym * dt * 0.5);
+        out[2 * plane] = -rhoinvm * ((sum9(fm_[0], MZ_P) - (sum9(fm_[0], MZ_M))) / CFL + forcezm * dt * 0.5);
+      }
   for (int l = 0; l < 4; ++l) free(rest1[l]);
 }
+
+/* [8][3][NY][NX]: ux, uy, uz of plane z=0 as the last collide would have written them for every
+ * outcome of the reference's race (see oracle_collide_save) */
+double* oracle_wall_velocity_alt(oracle_state* s) { return s->u0_alt; }
 
 /* gpu_boundary, LBM.cu:1848-1961 */
 void oracle_boundary(oracle_state* s) {

@@ -84,6 +84,8 @@ def lib():
         for fn in ("oracle_current", "oracle_umax"):
             getattr(L, fn).argtypes = [C.c_void_p]
             getattr(L, fn).restype = C.c_double
+        L.oracle_wall_velocity_alt.restype = C.POINTER(C.c_double)
+        L.oracle_wall_velocity_alt.argtypes = [C.c_void_p]
         L.oracle_set_num_threads.argtypes = [C.c_int]
         L.oracle_set_num_threads.restype = None
         L.oracle_get_max_threads.restype = C.c_int
@@ -147,6 +149,14 @@ class Oracle:
     def set_fields(self, d: dict):
         for n, v in d.items():
             self.field(n)[...] = np.asarray(v, dtype=np.float64).reshape(self.shape)
+
+    def wall_velocity_alt(self) -> np.ndarray:
+        """[8][3][NY][NX]: (ux, uy, uz) of plane z=0 under every resolution of the reference's
+        read-after-write race (LBM.cu:664-667 vs 1711-1714): node z=1's rest population of h
+        (mask bit 0), hn (bit 1), temp (bit 2) read AFTER its collision instead of before.  Mask 0
+        is the canonical one the fields hold."""
+        ptr = lib().oracle_wall_velocity_alt(self._h)
+        return np.ctypeslib.as_array(ptr, shape=(8, 3, self.p.ny, self.p.nx))
 
     def population(self, lattice: str, which: int) -> np.ndarray:
         """which 0: rest X0[NZ][NY][NX]; 1: X1[26][NZ][NY][NX]; 2: X2 (LBM.cu:17-30)."""

@@ -1,6 +1,13 @@
 """Generates tests/golden/ref_*.npz from the REFERENCE's own kernels.  Run on the GPU box:
 
-    python tests/golden/make_golden.py gpurun_out/golden
+    python tests/golden/make_golden.py gpurun_out/golden [NXxNYxNZ ...]
+
+Without a grid: the reference's own compile-time grid 50x8x51, cases G1-G7 below.  With grids:
+the second build(s) of the reference's kernels that oracle/build_ref.sh makes for other grids
+(sed on the temporary copy of LBM.h:32-35,40-42 only) -> ref_<grid>_g{1,2,4,5}_full.npz.  These
+pin the oracle on more than one size and cover what 50x8x51 cannot: rows of more than one
+64-node tile (130 = three tiles, the x+-1 pull across a tile boundary) and channels taller than
+the 66 planes the cyclic-reduction z solve handles (83 planes: the serial Thomas sweep).
 
 It drives oracle/_ref/ref_driver (built by oracle/build_ref.sh from /root/reference: the
 reference's LBM.cu / poisson.cu kernels compiled for gfx950) on the reference's compile-time
@@ -64,7 +71,87 @@ def io_fields(seed=6):
     return f
 
 
+def set_grid(nx, ny, nz):
+    global NX, NY, NZ, SHAPE, N
+    NX, NY, NZ = nx, ny, nz
+    SHAPE = (NZ, NY, NX)
+    N = NX * NY * NZ
+
+
+def extra_grid(outdir, grid):
+    """G1 (init + 1/5/20 steps), G2 (0/1/2/50), G4 and G5 on another compile-time grid."""
+    nx, ny, nz = (int(v) for v in grid.split("x"))
+    set_grid(nx, ny, nz)
+    os.makedirs(outdir, exist_ok=True)
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver_" + grid)
+    tmp = tempfile.mkdtemp()
+
+    def run(*args):
+        print("+ ref_driver_" + grid, *args, flush=True)
+        subprocess.check_call([drv, tmp, *args])
+
+    def trace(path, n):
+        return np.fromfile(path, dtype=np.float64).reshape(n, 2, NZ)
+
+    p = O.default_params(NX, NY, NZ)  # Lx = NX dx, Ly = NY dy, Lz = (NZ-1) dz: what build_ref.sh wrote
+    marks1 = (1, 5, 20)
+    run("init", "g1", *[str(m) for m in marks1])
+    g1 = {"marks": np.array(marks1), "grid": np.array([NX, NY, NZ])}
+    init = read_bin(os.path.join(tmp, "g1_init.bin"))
+    for tag, f in [("init", init)] + [(f"step{m}", read_bin(os.path.join(tmp, f"g1_step{m}.bin"))) for m in marks1]:
+        for k, v in f.items():
+            g1[f"{tag}_{k}"] = v
+    g1["current"] = np.array([read_current(os.path.join(tmp, f"g1_step{m}.bin")) for m in marks1])
+    g1["init_trace"] = trace(os.path.join(tmp, "g1_init_trace.bin"), 501)
+    g1["step_trace"] = trace(os.path.join(tmp, "g1_step_trace.bin"), marks1[-1])
+    np.savez_compressed(os.path.join(outdir, f"ref_{grid}_g1_full.npz"), **g1)
+
+    start = O.perturb_fields(p, init)
+    inp = os.path.join(tmp, "g2_in.bin")
+    write_bin(inp, start)
+    run("fields", inp, "g2", "1", "2", "50")
+    g2 = {"marks": np.array([1, 2, 50]), "grid": np.array([NX, NY, NZ])}
+    for k, v in start.items():
+        g2["input_" + k] = v
+    for m in (0, 1, 2, 50):
+        f = read_bin(os.path.join(tmp, f"g2_step{m}.bin"))
+        for k, v in f.items():
+            g2[f"step{m}_{k}"] = v
+    g2["current"] = np.array([read_current(os.path.join(tmp, f"g2_step{m}.bin")) for m in (1, 2, 50)])
+    g2["step_trace"] = trace(os.path.join(tmp, "g2_step_trace.bin"), 51)
+    np.savez_compressed(os.path.join(outdir, f"ref_{grid}_g2_full.npz"), **g2)
+
+    run("kernels", inp, "g4")
+    npop = 4 * 27 * NZ * 3 * NX
+    g4 = {}
+    for stage in ("step1", "collide", "boundary", "stream", "bc_charge"):
+        a = np.fromfile(os.path.join(tmp, f"g4_{stage}.bin"), dtype=np.float64)
+        assert a.size == npop, (stage, a.size)
+        g4[stage] = a.reshape(4, 27, NZ, 3, NX)
+    f0 = read_bin(os.path.join(tmp, "g4_fields0.bin"))
+    for k in O.FIELDS:
+        g4["fields0_" + k] = f0[k]
+    np.savez_compressed(os.path.join(outdir, f"ref_{grid}_g4_full.npz"), **g4)
+
+    rng = np.random.default_rng(5)
+    f5 = {k: np.zeros(SHAPE) for k in O.FIELDS}
+    f5["c"] = 0.01 * (1 + 0.2 * rng.random(SHAPE))
+    f5["cn"] = 0.01 * (1 + 0.2 * rng.random(SHAPE))
+    inp5 = os.path.join(tmp, "g5_in.bin")
+    write_bin(inp5, f5)
+    run("poisson", inp5, "g5")
+    out5 = read_bin(os.path.join(tmp, "g5.bin"))
+    g5 = {"grid": np.array([NX, NY, NZ])}
+    for k in ("c", "cn"):
+        g5["input_" + k] = f5[k]
+    for k in ("phi", "Ex", "Ey", "Ez"):
+        g5["out_" + k] = out5[k]
+    np.savez_compressed(os.path.join(outdir, f"ref_{grid}_g5_full.npz"), **g5)
+    print("golden vectors of grid", grid, "written to", outdir)
+
+
 def main(outdir):
+    set_grid(50, 8, 51)
     os.makedirs(outdir, exist_ok=True)
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     tmp = tempfile.mkdtemp()
@@ -181,4 +268,9 @@ def main(outdir):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/golden")
+    out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/golden"
+    if len(sys.argv) > 2:
+        for g in sys.argv[2:]:
+            extra_grid(out, g)
+    else:
+        main(out)

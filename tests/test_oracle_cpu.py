@@ -338,3 +338,112 @@ def test_golden_G4_per_kernel_vectors(O):
         ref = g[stage + "_sample"]
         scale = np.abs(ref).max(axis=(1, 2, 3, 4), keepdims=True)
         assert (np.abs(sample - ref) / scale).max() <= 1e-13, stage
+
+
+# ---- second and third grid of the reference's own kernels -----------------------------------
+# oracle/build_ref.sh NXxNYxNZ rebuilds the reference with NX, NY, NZ, Lx, Ly, Lz rewritten by sed
+# in the TEMPORARY copy of LBM.h (lines 32-35, 40-42); make_golden.extra_grid /
+# pack_golden.pack_extra turn its runs on the MI355X into tests/golden/ref_<grid>.npz.  130x6x19:
+# rows of three 64-node tiles (the x+-1 pull across a tile boundary), NX > 128.  70x6x83: two
+# tiles, a channel taller than 66 planes (serial Thomas z solve in the HIP path, NE = 164 = 4*41
+# in the reference's FFT).
+EXTRA_GRIDS = ["130x6x19", "70x6x83"]
+
+
+def _extra(O, grid):
+    g = _need(f"ref_{grid}.npz")
+    nx, ny, nz = (int(v) for v in g["grid"])
+    return g, O.default_params(nx, ny, nz)
+
+
+def _check_race_aware(O, o, got, want, ys, where):
+    """_check for a run of the reference's own kernels in which its read-after-write race may have
+    gone either way: the z==0 thread reads node z=1's rest populations (LBM.cu:664-667) which the
+    z=1 thread overwrites in the same launch (LBM.cu:1711-1714).  Only ux, uy, uz of plane z=0 see
+    it.  Everything else is compared as usual; on plane 0 every node must carry the canonical
+    (pre-collision) value or one of the 7 other outcomes (h0, hn0, temp0 of node z=1 each read
+    before or after its collision), which the oracle also computes.  Returns the number of nodes
+    that took a non-canonical outcome (20 of 210 at step 2 on 70x6x83: two 10-thread blocks)."""
+    u = ("ux", "uy", "uz")
+    cut = lambda d: {k: (v[1:] if k in u else v) for k, v in d.items()}  # noqa: E731
+    _check(O.rel_l2(cut(got), cut(want)), where)
+    alt = o.wall_velocity_alt()[:, :, ys, :]  # [8 outcomes][3][rows][nx]; outcome 0 is the canonical one
+    scale = max(np.abs(want[k]).max() for k in u)
+    d_pre = np.max([np.abs(got[k][0] - want[k][0]) for k in u], axis=0)
+    d_any = np.min([np.max([np.abs(alt[m, i] - want[k][0]) for i, k in enumerate(u)], axis=0) for m in range(8)], axis=0)
+    assert (d_any <= TOL_U * scale).all(), (where, "wall-plane velocity is no outcome of the race", d_pre.max(), d_any.max())
+    return int((d_pre > TOL_U * scale).sum())
+
+
+@pytest.mark.parametrize("grid", EXTRA_GRIDS)
+def test_golden_extra_grid_G1_init_and_steps(O, grid):
+    g, p = _extra(O, grid)
+    o = O.Oracle(p)
+    o.initialization_shifts(g["g1_init_shifts"])
+    col = lambda d: {k: v[:, 0, 0] for k, v in d.items()}  # noqa: E731
+    groups = {k: v for k, v in O.GROUPS.items() if k != "u"}
+    _check(O.rel_l2(col(o.fields()), {k: g["g1_init_" + k] for k in O.FIELDS}, groups), "init")
+    o.init_equilibrium()
+    done = 0
+    for i, mark in enumerate(int(m) for m in g["g1_marks"]):
+        o.step_shifts(g["g1_step_shifts"][done:mark])
+        done = mark
+        _check(O.rel_l2(col(o.fields()), {k: g[f"g1_step{mark}_{k}"] for k in O.FIELDS}), f"step {mark}")
+        want = float(g["g1_current"][i])
+        assert abs(o.current() - want) <= 1e-11 * abs(want), (mark, o.current(), want)
+
+
+@pytest.mark.parametrize("grid", EXTRA_GRIDS)
+def test_golden_extra_grid_G2_perturbed_3d_run(O, grid):
+    g, p = _extra(O, grid)
+    ys = list(g["ysel"])
+    o = O.Oracle(p)
+    o.gpu_initialization()
+    o.set_fields({k: g["g2_input_" + k] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+    sub = lambda d: {k: v[:, ys, :] for k, v in d.items()}  # noqa: E731
+    o.fast_poisson(float(g["g2_shifts"][0]))
+    _check(O.rel_l2(sub(o.fields()), {k: g["g2_step0_" + k] for k in O.FIELDS}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]}), "step 0")
+    o.init_equilibrium()
+    done = 0
+    raced = 0
+    for mark in (int(m) for m in g["g2_marks"]):
+        o.step_shifts(g["g2_shifts"][1 + done : 1 + mark])
+        done = mark
+        raced += _check_race_aware(O, o, sub(o.fields()), {k: g[f"g2_step{mark}_{k}"] for k in O.FIELDS}, ys, f"step {mark}")
+    print(f"{grid}: wall nodes where the reference's run took the other outcome of its race: {raced}")
+
+
+@pytest.mark.parametrize("grid", EXTRA_GRIDS)
+def test_golden_extra_grid_G4_per_kernel_and_G5_poisson(O, grid):
+    import importlib.util
+
+    g, p = _extra(O, grid)
+    spec = importlib.util.spec_from_file_location("pack_golden", os.path.join(os.path.dirname(golden_path("x")), "pack_golden.py"))
+    pk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pk)
+    o = O.Oracle(p)
+    o.gpu_initialization()
+    o.set_fields({k: g["g2_input_" + k] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+    o.fast_poisson(float(g["g4_shift"]))
+    o.init_equilibrium()
+    zs, xs = list(g["g4_zsel"]), list(g["g4_xsel"])
+    if p.nx > 65:
+        assert 63 in xs and 64 in xs  # both sides of a 64-node tile boundary are sampled
+    for stage, call, which in pk.G4_STAGES:
+        getattr(o, call)()
+        got = pk.oracle_pops(o, which)
+        s1, s2 = got.sum(axis=(2, 3, 4)), (got * got).sum(axis=(2, 3, 4))
+        assert np.abs(s1 - g[f"g4_{stage}_sum"]).max() <= 1e-12 * np.abs(g[f"g4_{stage}_sum"]).max(), stage
+        assert np.abs(s2 - g[f"g4_{stage}_sumsq"]).max() <= 1e-12 * np.abs(g[f"g4_{stage}_sumsq"]).max(), stage
+        sample = got[:, :, zs][:, :, :, :, xs]
+        ref = g[f"g4_{stage}_sample"]
+        scale = np.abs(ref).max(axis=(1, 2, 3, 4), keepdims=True)
+        assert (np.abs(sample - ref) / scale).max() <= 1e-13, stage
+    # G5
+    ys = list(g["ysel"])
+    o = O.Oracle(p)
+    o.gpu_initialization()
+    o.set_fields({"c": g["g5_input_c"], "cn": g["g5_input_cn"]})
+    o.fast_poisson(float(g["g5_shift"]))
+    got = {k: o.field(k)[:, ys, :] for k in ("phi", "Ex", "Ey", "Ez")}
+    _check(O.rel_l2(got, {k: g["g5_out_" + k] for k in got}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]}), "poisson")

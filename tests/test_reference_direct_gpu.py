@@ -1,0 +1,205 @@
+"""HIP path vs the outputs of the REFERENCE's own kernels, directly (no oracle in between), for the
+coupled run where phi feeds back into every field.
+
+The only thing that separates the two runs is the reference's DC-mode leak (poisson.cu:177: mode
+(0,0,0) is divided by mu = 1 instead of being zeroed, so every fast_Poisson returns the exact
+interior phi plus ONE constant, the FFT library's rounding residue).  The fixtures
+carry that constant for every single solve of the reference's run (`*_shifts`, measured by
+tests/golden/pack_golden.py from phi columns the reference driver traced).  The test drives the
+product through its public C ABI exactly like main.cu:189-200 does - stream_collide_save,
+fast_Poisson - and after every solve adds the reference's constant to the interior planes of the
+returned phi and re-evaluates E from it on the host with the reference's own formula
+(poisson.cu:45-69), writing both back with ekpnp_set_field.  The product is not changed in any way;
+nothing under oracle/ computes a number here (only its rel-L2 helper is used).
+
+Cases: the reference's default 50x8x51 run G1 (initialization() with all 501 PB sweeps, then
+1/5/20/100 steps) and the perturbed 3-D run G2 (0/1/2/50 steps), and the same two runs on the two
+extra compile-time grids 130x6x19 (three 64-node tiles per row) and 70x6x83 (serial z solve).
+Tolerances as in test_parity_gpu.py: 1e-9 per field group, 1e-7 for the velocity group."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+TOL, TOL_U = 1e-9, 1e-7
+_REPORT = []
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_report():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report_reference_direct.json"), "w") as f:
+            json.dump(_REPORT, f, indent=1)
+    except OSError:
+        pass
+
+
+def _need(name):
+    path = golden_path(name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} missing")
+    return np.load(path)
+
+
+def reference_efield(phi, p):
+    """gpu_efield + gpu_bc, poisson.cu:45-69: 0.5*(phi(-1) - phi(+1))/d, periodic in every axis,
+    then Ez of a wall plane copies its interior neighbour."""
+    ex = 0.5 * (np.roll(phi, 1, 2) - np.roll(phi, -1, 2)) / p.dx
+    ey = 0.5 * (np.roll(phi, 1, 1) - np.roll(phi, -1, 1)) / p.dy
+    ez = 0.5 * (np.roll(phi, 1, 0) - np.roll(phi, -1, 0)) / p.dz
+    ez[0], ez[-1] = ez[1], ez[-2]
+    return ex, ey, ez
+
+
+def inject_leak(s, p, shift):
+    """phi_ref = phi_exact + shift on the interior planes; E_ref = E(phi_ref)."""
+    phi = s.get_field("phi")
+    phi[1:-1] += shift
+    ex, ey, ez = reference_efield(phi, p)
+    s.set_field("phi", phi)
+    s.set_field("Ex", ex)
+    s.set_field("Ey", ey)
+    s.set_field("Ez", ez)
+
+
+def _check(O, name, mark, got, want, groups=None):
+    """Every group as usual - except that the velocity group is taken over the planes z >= 1 and
+    plane z = 0 of u is checked node by node.  Reason: the reference's z==0 thread reads node z=1's
+    rest populations (LBM.cu:664-667) while the z=1 thread overwrites them in the same launch
+    (LBM.cu:1711-1714).  The product implements the canonical outcome (pre-collision values,
+    SURVEY.md 8(c)); in the reference's own run on 70x6x83 two 10-thread blocks (20 of 210 sampled
+    wall nodes, step 2) saw a mix - tests/test_oracle_cpu.py proves node by node that those values
+    are one of the 8 possible outcomes.  Here: at most 10 % of the wall nodes may deviate, and by no
+    more than the race can explain (1e-4 of |u|; SURVEY measured <= 2.4e-6 rel-L2)."""
+    groups = groups or O.GROUPS
+    u = ("ux", "uy", "uz")
+    cut = lambda d: {k: (v[1:] if k in u else v) for k, v in d.items()}  # noqa: E731
+    err = O.rel_l2(cut(got), cut(want), groups)
+    rec = {"test": name, "mark": str(mark), "rel_l2": err}
+    if "u" in groups and all(k in got for k in u):
+        scale = max(np.abs(want[k]).max() for k in u)
+        d0 = np.max([np.abs(got[k][0] - want[k][0]) for k in u], axis=0)
+        off = d0 > TOL_U * scale
+        rec["wall_plane_u"] = {"nodes": int(d0.size), "raced_in_reference": int(off.sum()), "max_rel_dev": float(d0.max() / scale) if scale > 0 else 0.0}
+        assert off.mean() <= 0.10 and (scale == 0 or d0.max() <= 1e-4 * scale), (name, mark, rec)
+    _REPORT.append(rec)
+    bad = {k: v for k, v in err.items() if not v <= (TOL_U if k == "u" else TOL)}
+    assert not bad, (name, mark, err)
+
+
+class _Gold:
+    """Uniform view of the default-grid fixtures (ref_g1.npz / ref_g2.npz) and of an extra grid's
+    single file (ref_<grid>.npz, keys prefixed g1_ / g2_)."""
+
+    def __init__(self, pkg, grid):
+        if grid == "50x8x51":
+            self.g1, self.g2 = _need("ref_g1.npz"), _need("ref_g2.npz")
+            self.k1 = self.k2 = ""
+            self.p = pkg.default_params(50, 8, 51)
+            self.p.Lx, self.p.Ly, self.p.Lz = 0.5e-6, 0.08e-6, 0.5e-6  # literals of LBM.h:40-42
+            self.ys = list(self.g2["ysel"])
+            self.step_shifts1, self.shifts2 = self.g1["step_shifts"], self.g2["shifts"]
+            self.init_shifts = self.g1["init_shifts"]
+        else:
+            g = _need(f"ref_{grid}.npz")
+            self.g1 = self.g2 = g
+            self.k1, self.k2 = "g1_", "g2_"
+            nx, ny, nz = (int(v) for v in g["grid"])
+            self.p = pkg.default_params(nx, ny, nz)  # Lx = NX dx ... as oracle/build_ref.sh wrote them
+            self.ys = list(g["ysel"])
+            self.step_shifts1, self.shifts2 = g["g1_step_shifts"], g["g2_shifts"]
+            self.init_shifts = g["g1_init_shifts"]
+        self.marks1 = [int(m) for m in self.g1[self.k1 + "marks"]]
+        self.marks2 = [int(m) for m in self.g2[self.k2 + "marks"]]
+
+
+GRIDS = ["50x8x51", "130x6x19", "70x6x83"]
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_default_run_G1_hip_vs_reference_direct(pkg, O, grid):
+    """initialization() (LBM.cu:68-109, 501 PB sweeps, driven through the split entry points so
+    that the leak of every sweep's solve can be injected) + the time loop of main.cu:189-200."""
+    G = _Gold(pkg, grid)
+    p = G.p
+    name = f"G1_direct[{grid}]"
+    col = lambda d: {k: v[:, 0, 0] for k, v in d.items()}  # noqa: E731  (x-y uniform run: z profiles)
+    with pkg.Solver(p) as s:
+        s.call("init_fields")       # gpu_initialization, LBM.cu:76
+        s.call("pbe_begin")         # phi_old <- phi, LBM.cu:79-86
+        for sh in G.init_shifts:    # LBM.cu:89-106
+            s.call("pbe_concentrations")
+            s.fast_Poisson()
+            inject_leak(s, p, float(sh))
+            s.call("pbe_relax")
+        s.call("pbe_end")
+        f = s.fields()
+        for k in ("rho", "c", "cn", "phi", "T", "Ez"):  # the reference's fields are bit-exactly x-y uniform
+            assert np.abs(f[k] - f[k][:, :1, :1]).max() <= 1e-12 * np.abs(f[k]).max(), k
+        _check(O, name, "init", col(f), {k: G.g1[f"{G.k1}init_{k}"] for k in O.FIELDS}, {k: v for k, v in O.GROUPS.items() if k != "u"})
+        assert not np.any(f["ux"]) and not np.any(f["uz"])
+        s.init_equilibrium()
+        done = 0
+        for mark in G.marks1:
+            for k in range(done, mark):
+                s.stream_collide_save()
+                s.fast_Poisson()
+                inject_leak(s, p, float(G.step_shifts1[k]))
+            done = mark
+            _check(O, name, mark, col(s.fields()), {k: G.g1[f"{G.k1}step{mark}_{k}"] for k in O.FIELDS})
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_perturbed_run_G2_hip_vs_reference_direct(pkg, O, grid):
+    G = _Gold(pkg, grid)
+    p = G.p
+    name = f"G2_direct[{grid}]"
+    sub = lambda d: {k: v[:, G.ys, :] for k, v in d.items()}  # noqa: E731
+    with pkg.Solver(p) as s:
+        s.call("init_fields")
+        s.set_fields({k: G.g2[f"{G.k2}input_{k}"] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+        s.fast_Poisson()
+        inject_leak(s, p, float(G.shifts2[0]))
+        _check(O, name, 0, sub(s.fields()), {k: G.g2[f"{G.k2}step0_{k}"] for k in O.FIELDS}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
+        s.init_equilibrium()
+        done = 0
+        for mark in G.marks2:
+            for k in range(done, mark):
+                s.stream_collide_save()
+                s.fast_Poisson()
+                inject_leak(s, p, float(G.shifts2[1 + k]))
+            done = mark
+            _check(O, name, mark, sub(s.fields()), {k: G.g2[f"{G.k2}step{mark}_{k}"] for k in O.FIELDS})
+
+
+@pytest.mark.parametrize("grid", GRIDS[1:])
+def test_extra_grid_G5_poisson_and_first_step_moments(pkg, O, grid):
+    """fast_Poisson alone on random charges (HIP phi == reference phi minus its DC constant) and the
+    moments written by the first collide on the G2 input, which do not see phi at all."""
+    G = _Gold(pkg, grid)
+    g, p = G.g2, G.p
+    with pkg.Solver(p) as s:
+        s.set_field("c", g["g5_input_c"])
+        s.set_field("cn", g["g5_input_cn"])
+        s.fast_Poisson()
+        phi = s.get_field("phi")[:, G.ys, :]
+    d = g["g5_out_phi"][1:-1] - phi[1:-1]
+    assert np.abs(d - float(g["g5_shift"])).max() < 1e-15
+    assert np.array_equal(phi[0], g["g5_out_phi"][0]) and np.array_equal(phi[-1], g["g5_out_phi"][-1])
+    with pkg.Solver(p) as s:
+        s.call("init_fields")
+        s.set_fields({k: g["g2_input_" + k] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+        s.fast_Poisson()
+        s.init_equilibrium()
+        s.step(1)
+        f = {k: s.get_field(k)[:, G.ys, :] for k in ("rho", "c", "cn", "T")}
+    err = O.rel_l2(f, {k: g["g2_step1_" + k] for k in f}, {k: [k] for k in f})
+    _REPORT.append({"test": f"G2_step1_moments[{grid}]", "mark": "1", "rel_l2": err})
+    assert max(err.values()) < 1e-13, err

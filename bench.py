@@ -4,9 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg1|NXxNYxNZ]
 
 N=1: cfg3 of BASELINE.json (512x512x512, four D3Q27 lattices + Poisson) when it fits the GPU,
-otherwise cfg2 (256^3, f+h+hn).  N>1 (launched by torch.distributed.run, one rank per GPU):
-weak scaling, every rank owns a 512x512x512 slab of a 512x512x(512 N) channel (cfg4 at N=2),
-z-slab decomposition with halo exchange over RCCL.
+otherwise cfg2 (256^3, f+h+hn).  N>1 (one rank per GPU: launched by torch.distributed.run, or by
+bench.py itself when invoked plainly - the ranks are then child processes): weak scaling, every
+rank owns a 512x512x512 slab of a 512x512x(512 N) channel (cfg4 at N=2), z-slab decomposition,
+halo exchange over RCCL inside libekpnp.so (ekpnp_slab_attach_comm); torch.distributed (gloo)
+is the control plane only: rendezvous, barrier, max over ranks.
 
 One JSON line on rank 0.  `value` counts lattice-node updates of all ranks per wall second of
 the timed region (inputs resident in HBM, barrier + device sync on both sides, max over ranks).
@@ -23,7 +25,12 @@ import os
 import sys
 import time
 
-import numpy as np
+# thread placement of the CPU-baseline leg; an OpenMP runtime reads these once, when
+# it starts, so they are set before anything that brings one in is imported
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -112,35 +119,75 @@ def apply_perturbation(sol, O, p):
     sol.set_field("uz", 0.5e-4 * sZ**2 * np.cos(X) * np.cos(Y))
 
 
-def cpu_baseline(nl: int, budget_s: float = 15.0):
-    """The CPU oracle (kind 'port': our restatement of the reference's step; the reference has
-    no CPU path) on all host cores, on a bounded sample of the same physics."""
-    O = G.load_oracle()
-    shape = (128, 128, 65)
-    p = O.default_params(*shape)
-    p.pb_iterations = 3
-    if nl < 4:
-        p.Ra = 0.0
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_oracle(O, p, threads: int, budget_s: float, perturb: bool):
+    """MLUPS of the oracle's full step on `threads` cores, about budget_s seconds of it."""
     o = O.Oracle(p)
+    used = O.set_threads(threads)
+    o.threads = used
     o.initialization()
-    o.set_fields(O.perturb_fields(p, o.fields()))
-    o.fast_poisson()
+    if perturb:
+        o.set_fields(O.perturb_fields(p, o.fields()))
+        o.fast_poisson()
     o.init_equilibrium()
     o.step(1)
     t0 = time.perf_counter()
     o.step(1)
     per = time.perf_counter() - t0
-    k = max(2, min(200, int(budget_s / max(per, 1e-3))))
+    k = max(2, min(500, int(budget_s / max(per, 1e-4))))
     t0 = time.perf_counter()
     o.step(k)
     dt = time.perf_counter() - t0
-    cores = o.threads
+    n = o.n
+    o.close()
+    return n * k / dt / 1e6, k, dt, used
+
+
+def cpu_baseline(nl: int, budget_s: float = 20.0):
+    """BASELINE.md §3.  The reference has no CPU path (every compute routine is a __global__
+    kernel), so the number beside the GPU line is the CPU oracle (kind "port": our restatement of
+    the same step, test infrastructure) timed on this box's host cores, after the timed GPU region:
+      * the multi-lattice sample: the bench's physics (four lattices + Poisson) on 128x128x65,
+        all cores - this is `value`;
+      * cfg1 of BASELINE.json (64x64x64, fluid lattice only, body-force channel) on all cores and
+        on ONE core.
+    Bounded to about budget_s seconds in total."""
+    O = G.load_oracle()
+    cores = O.host_cores()
+    legs = []
+    shape = (128, 128, 65)
+    p = O.default_params(*shape)
+    p.pb_iterations = 3
+    if nl < 4:
+        p.Ra = 0.0
+    v, k, dt, used = _time_oracle(O, p, cores, 0.5 * budget_s, True)
+    main_leg = {"workload": f"{shape[0]}x{shape[1]}x{shape[2]} D3Q27 x4 lattices + Poisson", "cores": used, "value": round(v, 3), "steps": k, "seconds": round(dt, 2)}
+    legs.append(main_leg)
+    p1 = O.default_params(64, 64, 64)
+    p1.n_lattices, p1.chargeinf, p1.Ra, p1.TH, p1.exf, p1.pb_iterations = 1, 0.0, 0.0, 0.0, 1e9, 1
+    for th in (cores, 1):
+        v1, k1, dt1, used1 = _time_oracle(O, p1, th, 0.25 * budget_s, False)
+        legs.append({"workload": "cfg1: 64x64x64 D3Q27 fluid lattice only (exf = 1e9, no ions)", "cores": used1, "value": round(v1, 3), "steps": k1,
+                     "seconds": round(dt1, 2), "achieved_GBps": round(v1 * 1e6 * b_alg_step(1) / 1e9, 2)})
     return {
-        "value": round(o.n * k / dt / 1e6, 3),
+        "value": main_leg["value"],
         "unit": "MLUPS",
-        "cores": cores,
+        "cores": main_leg["cores"],
         "kind": "port",
-        "sample": f"{shape[0]}x{shape[1]}x{shape[2]} D3Q27 x4 lattices + Poisson, {k} steps, OpenMP oracle ({dt:.1f} s)",
+        "sample": f"{main_leg['workload']}, {k} steps, OpenMP oracle ({dt:.1f} s)",
+        "cpu_model": cpu_model(),
+        "threads_available": cores,
+        "pinning": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
+        "legs": legs,
     }
 
 
@@ -177,6 +224,46 @@ def spawn_ranks(n: int, argv: list) -> int:
     return rc
 
 
+def pb_profile_from_product(pkg, p):
+    """z profiles (phi, c, cn) of the Poisson-Boltzmann start, made by the PRODUCT:
+    ekpnp_initialization_converged (the reference's Picard sweeps, LBM.cu:89-106, with a damping
+    that converges on tall channels where PB_omega = 0.05 diverges) on a narrow 16x16 replica -
+    the start is x-y uniform, so NX and NY do not enter.  Channels taller than 257 planes: the two
+    double layers (lambda_D = 9.2 dz) are farther apart than exp(-128/9.2) ~ 1e-6 of the wall
+    potential, so the replica has 257 planes and the planes in between carry its mid-plane values.
+    Returns (profiles dict of [nz] arrays, note)."""
+    nzr = p.nz if p.nz <= 257 else 257
+    q = pkg.default_params(16, 16, nzr)
+    for k in ("chargeinf", "voltage", "voltage2", "eps", "kB", "electron", "roomT", "convertCtoCharge", "PB_omega", "TH", "rho0", "dz"):
+        setattr(q, k, getattr(p, k))
+    q.Lz = (nzr - 1) * q.dz
+    with pkg.Solver(q) as r:
+        sweeps, res = r.initialization_converged(1e-9, 50000)
+        prof = {k: r.get_field(k)[:, 0, 0].copy() for k in ("phi", "c", "cn")}
+    if nzr != p.nz:
+        h = nzr // 2
+        prof = {k: np.concatenate([v[:h], np.full(p.nz - 2 * h, v[h]), v[nzr - h:]]) for k, v in prof.items()}
+    note = (f"ekpnp_initialization_converged on a 16x16x{nzr} replica ({sweeps} PB sweeps, residual {res:.1e})"
+            + (", mid-plane values between the two double layers" if nzr != p.nz else ""))
+    return prof, note
+
+
+def product_pb_state(sol, p, prof):
+    """the fields gpu_initialization + the PB loop leave (LBM.cu:111-128,139-146), from z profiles"""
+    nz, ny, nx = sol.shape
+    z = (np.arange(nz) + sol.z0).astype(np.float64)
+    sl = slice(sol.z0, sol.z0 + nz)
+    col = lambda v: np.broadcast_to(np.asarray(v, dtype=np.float64)[:, None, None], sol.shape)  # noqa: E731
+    sol.set_field("phi", col(prof["phi"][sl]))
+    sol.set_field("c", col(prof["c"][sl]))
+    sol.set_field("cn", col(prof["cn"][sl]))
+    sol.set_field("rho", col(np.full(nz, p.rho0)))
+    sol.set_field("T", col(p.TH * (p.Lz - p.dz * z) / p.Lz))  # LBM.cu:127
+    zero = np.zeros(sol.shape)
+    for k in ("ux", "uy", "uz", "Ex", "Ey", "Ez"):
+        sol.set_field(k, zero)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,10 +275,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-place", action="store_true", help="one population buffer per lattice (ekpnp_params.in_place): 0.57x the memory of cfg3")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="transport of the N>1 path; gloo (host-staged) only to rehearse the multi-rank flow")
-    ap.add_argument("--single-device", action="store_true", help="rehearsal: put every rank on device 0")
+                    help="N>1 data path.  nccl: the library's own RCCL transport (ekpnp_slab_attach_comm).  gloo: the host-staged "
+                         "python transport of slab.py, only to rehearse the multi-rank flow on a one-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: put every rank on device 0 (needs --backend gloo for N>1)")
     ap.add_argument("--force-slab", action="store_true",
-                    help="N=1 only: run the multi-rank code path (split calls + RCCL exchanges, the ring closing on the same rank)")
+                    help="N=1 only: run the multi-rank code path (split calls, comm stream, RCCL exchanges, the ring closing on the same rank)")
+    ap.add_argument("--dry-run", action="store_true", help="check the launch plumbing only: rendezvous, barrier, one JSON line; no GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -207,36 +296,41 @@ def main():
 
     import torch
 
+    # control plane (rendezvous, barrier, max over ranks): torch.distributed over gloo, CPU tensors.
+    # The DATA path of --backend nccl is RCCL inside libekpnp.so, not torch.
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: WPS440
+
+        dist.init_process_group("gloo")
+    if args.dry_run:
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "MLUPS (full EK-PNP step)", "value": None, "unit": "MLUPS", "n_gpus": world, "dry_run": True}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     if args.single_device:
         local_rank = 0
+    if world > 1 and args.backend == "nccl" and args.single_device:
+        raise SystemExit("bench.py: RCCL refuses two ranks on one device; rehearse with --backend gloo --single-device")
     torch.cuda.set_device(local_rank)
     pkg = G.load_package()
 
     free_b, total_b = torch.cuda.mem_get_info()
     wname, (nx, ny, nz), nl, use_in_place = parse_workload(args.workload, free_b, args.in_place)
-    dist = None
+    slab_path = world > 1 or args.force_slab
+    native = slab_path and args.backend == "nccl"
     saved_stdout = None
-    if world > 1 or args.force_slab:
-        import torch.distributed as dist  # noqa: WPS440
-
+    if slab_path:
         # RCCL prints a version banner on the C-level stdout when its first communicator is made;
         # stdout is for the ONE JSON line, so fd 1 points at stderr until that line is printed
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-
-        kw = {}
-        if "RANK" not in os.environ:  # plain `python bench.py --force-slab`
-            import socket
-
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            kw = {"init_method": f"tcp://127.0.0.1:{port}", "rank": 0, "world_size": 1}
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
-        else:
-            dist.init_process_group("gloo", **kw)
     nz_global = nz * world  # weak scaling: one cfg-sized slab per GPU
 
     p = pkg.default_params(nx, ny, nz_global)
@@ -250,30 +344,58 @@ def main():
     if use_in_place:
         p.in_place = 1
 
-    if dist is None:
-        sol = pkg.Solver(p)
-        runner = sol
-    else:
-        from ek_pnp_3d_amd.slab import DistributedSlab  # noqa: WPS433
-
-        # a rank that cannot build its slab (e.g. out of memory) must not leave the others
-        # waiting in a collective: agree on success before anybody enters the exchange
-        err = None
-        try:
-            runner = DistributedSlab(p, rank, world, dist)
-            sol = runner.solver
-        except Exception as e:  # noqa: BLE001
-            err = e
-        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+    def agree(err):
+        """a rank that failed (e.g. out of memory) must not leave the others waiting in a collective"""
+        if dist is None:
+            if err is not None:
+                raise SystemExit(f"bench.py: {err}")
+            return
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
             dist.destroy_process_group()
-            raise SystemExit(f"rank {rank}: slab creation failed on at least one rank: {err}")
+            raise SystemExit(f"rank {rank}: set-up failed on at least one rank: {err}")
 
     # untimed start-up (the reference's timer also starts after it, main.cu:161-186)
+    prof, ic_note = None, None
     if nz_global > 128 and nl > 1:
-        gouy_chapman_state(sol, p)
-        ic_note = "Gouy-Chapman double layers (initialization() diverges for NZ > ~180)"
+        prof, ic_note = pb_profile_from_product(pkg, p)  # before the big allocation, on this rank's own GPU
+
+    err, runner, sol = None, None, None
+    try:
+        if not slab_path:
+            sol = runner = pkg.Solver(p)
+            transport = "none (one context)"
+        elif native:
+            sol = runner = pkg.Solver(p, rank, world, slab=True)
+            transport = "RCCL inside libekpnp.so (ncclSend/ncclRecv ring + ncclAllGather, high-priority comm stream)"
+        else:
+            from ek_pnp_3d_amd.slab import DistributedSlab  # noqa: WPS433
+
+            if dist is None:  # --force-slab --backend gloo
+                import socket
+
+                import torch.distributed as dist  # noqa: WPS440
+
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            runner = DistributedSlab(p, rank, world, dist)
+            sol = runner.solver
+            transport = "torch.distributed gloo, host-staged (rehearsal)"
+    except Exception as e:  # noqa: BLE001
+        err = e
+    agree(err)
+    if native:
+        # ONE rank makes the RCCL id, the control plane hands it round, every rank attaches (collective)
+        ident = [pkg.comm_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(ident, src=0)
+        sol.attach_comm(ident[0])
+
+    if prof is not None:
+        product_pb_state(sol, p, prof)
     else:
         runner.initialization()
         ic_note = f"initialization() with {p.pb_iterations} PB sweeps"
@@ -299,7 +421,7 @@ def main():
     sol.kernel_timing(False)
 
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -320,11 +442,17 @@ def main():
             copy_gbs = sol.copy_bandwidth(min(2 << 30, free_now // 4))
         except Exception as exc:  # e.g. no room for the scratch buffers next to a 276 GB lattice
             print(f"copy-bandwidth probe skipped: {exc}", file=sys.stderr)
-        traffic = None
+        # HBM traffic of one launch from the PMC counters: NOT measured by this run (counters need
+        # rocprofv3 around the process) - the value of the committed profile of this workload, with
+        # where it comes from; null if the profile does not cover this workload
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(wname, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath)).get(wname, {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_src = {"file": "profiles/pmc_traffic.json", "profiled_in": rec.get("round"),
+                               "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of that committed profile, NOT measured by this run"}
             except Exception:
                 traffic = None
         out = {
@@ -344,10 +472,11 @@ def main():
                 "workload": f"{wname}: {nx}x{ny}x{nz_global} D3Q27 x{nl} lattices"
                 + (" + spectral Poisson" if nl > 1 else "")
                 + (f", z-slabs of {nz} planes over {world} GPUs" if world > 1 else "")
-                + (", multi-rank code path on one rank (RCCL ring to itself)" if world == 1 and dist is not None else ""),
+                + (", multi-rank code path on one rank (ring to itself)" if world == 1 and slab_path else ""),
                 "grid": [nx, ny, nz_global],
                 "lattices": nl,
                 "in_place": bool(p.in_place),
+                "transport": transport,
                 "ic": ic_note + (" + closed-form 3-D perturbation" if args.ic == "perturbed" else ""),
                 "b_alg_step_bytes_per_node": b_alg_step(nl),
                 "step_roofline_frac": round(b_alg_step(nl) * mlups / world * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
@@ -362,6 +491,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "copy_GBps": round(copy_gbs, 1) if copy_gbs else None,
                 "frac_of_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                 "bytes_per_node": b_alg_lbm(nl),

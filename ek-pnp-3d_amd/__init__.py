@@ -11,8 +11,13 @@ from .solver import (  # noqa: F401
     FIELDS,
     FIELD_ID,
     EkpnpError,
+    Group,
     Params,
     Solver,
+    TRANSPORT_AUTO,
+    TRANSPORT_COPY,
+    TRANSPORT_RCCL,
+    comm_unique_id,
     compute_parameters,
     default_params,
     exported_symbols,

@@ -118,9 +118,9 @@ KArgs Ctx::kargs() const {
   a.TH = p.TH;
   a.uw_multi = 2.0 * p.rho0 * p.uw / cs2 / p.CFL;  // LBM.cu:1896-1898 without the weight
   a.rhs = p.n_lattices > 1 ? work : nullptr;
-  a.rhs_scale = -p.convertCtoCharge / p.eps;
-  a.rhs_wall_lo = -p.voltage / p.dz / p.dz;
-  a.rhs_wall_hi = -p.voltage2 / p.dz / p.dz;
+  a.eps = p.eps;
+  a.rhs_wall_lo = p.voltage / p.dz / p.dz;    // poisson.cu:124
+  a.rhs_wall_hi = p.voltage2 / p.dz / p.dz;   // poisson.cu:134
   return a;
 }
 
@@ -133,7 +133,8 @@ PArgs Ctx::pargs() const {
   a.nx = p.nx; a.ny = p.ny; a.nz = p.nz; a.nxh = nxh; a.nzl = nzl; a.z0 = z0;
   a.plane = (long long)plane;
   a.F = p.convertCtoCharge; a.eps = p.eps; a.voltage = p.voltage; a.voltage2 = p.voltage2;
-  a.inv_dz2 = 1.0 / p.dz / p.dz;
+  a.rhs_wall_lo = p.voltage / p.dz / p.dz;
+  a.rhs_wall_hi = p.voltage2 / p.dz / p.dz;
   a.dx = p.dx; a.dy = p.dy; a.dz = p.dz;
   a.inv_nxny = 1.0 / ((double)p.nx * (double)p.ny);
   return a;
@@ -194,6 +195,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
     return bail(EKPNP_ERR_HIP);
   }
   c.own_stream = true;
+  if (hipGetDevice(&c.device) != hipSuccess) { c.err = "hipGetDevice failed"; return bail(EKPNP_ERR_HIP); }
   // In-place mode: one buffer per lattice with `shift` spare planes.  A sweep writes plane z of
   // the new state `shift` planes below (parity 0, bulk launches of `zchunk` planes in ascending z)
   // or above (parity 1, descending) where plane z of the old state lies; shift >= zchunk + 1
@@ -218,7 +220,8 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   // multiple of `skew` bytes inside a slightly larger allocation (EKPNP_FIELD_SKEW: tuning knob).
   static const size_t skew = std::getenv("EKPNP_FIELD_SKEW") ? (size_t)std::atoll(std::getenv("EKPNP_FIELD_SKEW")) : 4096;
   for (int i = 0; i < EKPNP_NFIELDS; ++i) {
-    if ((rc = dev_alloc(c, &c.fld_alloc[i], c.nloc * sizeof(double) + (size_t)EKPNP_NFIELDS * skew))) return bail(rc);
+    c.fld_bytes[i] = c.nloc * sizeof(double) + (size_t)EKPNP_NFIELDS * skew;
+    if ((rc = dev_alloc(c, &c.fld_alloc[i], c.fld_bytes[i]))) { c.fld_bytes[i] = 0; return bail(rc); }
     c.fld[i] = (double*)((char*)c.fld_alloc[i] + (size_t)i * skew);
     c.fld_owned[i] = true;
     if (hipMemsetAsync(c.fld[i], 0, c.nloc * sizeof(double), c.stream) != hipSuccess) { c.err = "hipMemsetAsync failed"; return bail(EKPNP_ERR_HIP); }
@@ -260,14 +263,21 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
     int rembed[2] = {p->ny, p->nx};      // real planes, dense
     int cembed[2] = {p->ny, c.nxh};      // half spectrum with the padded row pitch
     hipfftResult r = hipfftPlanMany(&c.plan_fwd, 2, n, rembed, 1, p->ny * p->nx, cembed, 1, p->ny * c.nxh, HIPFFT_D2Z, c.nzl);
-    if (r == HIPFFT_SUCCESS) r = hipfftPlanMany(&c.plan_inv, 2, n, cembed, 1, p->ny * c.nxh, rembed, 1, p->ny * p->nx, HIPFFT_Z2D, c.nzl);
-    if (r != HIPFFT_SUCCESS) { c.err = "hipfftPlanMany failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
+    if (r != HIPFFT_SUCCESS) { c.plan_fwd = 0; c.err = "hipfftPlanMany (D2Z) failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
+    c.have_fwd = true;
+    r = hipfftPlanMany(&c.plan_inv, 2, n, cembed, 1, p->ny * c.nxh, rembed, 1, p->ny * p->nx, HIPFFT_Z2D, c.nzl);
+    if (r != HIPFFT_SUCCESS) { c.plan_inv = 0; c.err = "hipfftPlanMany (Z2D) failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
+    c.have_inv = true;
     c.plans = true;
     hipfftSetStream(c.plan_fwd, c.stream);
     hipfftSetStream(c.plan_inv, c.stream);
+    // the work areas rocFFT allocated for the two plans are device memory held by the solver too
+    size_t ws = 0;
+    if (hipfftGetSize(c.plan_fwd, &ws) == HIPFFT_SUCCESS) c.bytes += ws;
+    ws = 0;
+    if (hipfftGetSize(c.plan_inv, &ws) == HIPFFT_SUCCESS) c.bytes += ws;
   }
-  build_cprime(c);
-  if (!c.err.empty()) return bail(EKPNP_ERR_NOMEM);
+  if ((rc = build_cprime(c))) return bail(rc);
   if (hipStreamSynchronize(c.stream) != hipSuccess || hipGetLastError() != hipSuccess) { c.err = "device initialisation failed"; return bail(EKPNP_ERR_HIP); }
   *out = h;
   return EKPNP_OK;
@@ -281,6 +291,7 @@ extern "C" int ekpnp_create_slab(const ekpnp_params* p, int rank, int nranks, ek
 extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (!ctx) return EKPNP_ERR_INVALID;
   Ctx& c = ctx->c;
+  team_detach(c);  // an attached communicator / comm stream goes first (no-op otherwise)
   if (c.stream) (void)hipStreamSynchronize(c.stream);
   for (int b = 0; b < 2; ++b)
     for (int l = 0; l < MAXL; ++l)
@@ -306,7 +317,8 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
     if (c.halo[k]) (void)hipFree(c.halo[k]);
     if (c.phi_halo[k]) (void)hipFree(c.phi_halo[k]);
   }
-  if (c.plans) { hipfftDestroy(c.plan_fwd); hipfftDestroy(c.plan_inv); }
+  if (c.have_fwd) hipfftDestroy(c.plan_fwd);
+  if (c.have_inv) hipfftDestroy(c.plan_inv);
   for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
   delete ctx;
@@ -338,7 +350,12 @@ extern "C" int ekpnp_bind_field(ekpnp_ctx* ctx, int id, double* dptr) {
   if (id < 0 || id >= EKPNP_NFIELDS || !dptr) return fail(c, "bad field id or NULL pointer");
   HIPCHK(c, hipStreamSynchronize(c.stream));
   HIPCHK(c, hipMemcpy(dptr, c.fld[id], c.nloc * sizeof(double), hipMemcpyDeviceToDevice));
-  if (c.fld_owned[id]) { (void)hipFree(c.fld_alloc[id]); c.fld_alloc[id] = nullptr; c.bytes -= c.nloc * sizeof(double); }
+  if (c.fld_owned[id]) {
+    (void)hipFree(c.fld_alloc[id]);
+    c.fld_alloc[id] = nullptr;
+    c.bytes -= c.fld_bytes[id];  // the whole allocation, skew pad included
+    c.fld_bytes[id] = 0;
+  }
   c.fld[id] = dptr;
   c.fld_owned[id] = false;
   c.rhs_ready = false;
@@ -440,10 +457,25 @@ static int poisson_single(Ctx& c) {
   return EKPNP_OK;
 }
 
+// A right-hand side the collide wrote from its registers is only trusted when both concentration
+// arrays are the library's own: caller-bound arrays (ekpnp_bind_field) may have been changed on the
+// device between the two calls, and the reference's fast_Poisson reads charge_gpu / chargen_gpu at
+// call time (poisson.cu:83,114-135).  Both producers evaluate poisson_rhs_value(): same bits.
+static inline void distrust_bound_rhs(Ctx& c) {
+  if (!c.fld_owned[EKPNP_C] || !c.fld_owned[EKPNP_CN]) c.rhs_ready = false;
+}
+
 extern "C" int ekpnp_fast_poisson(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.slab) return fail(c, "ekpnp_fast_poisson on a slab context: use ekpnp_poisson_stage1/2/3 with the halo transport");
+  distrust_bound_rhs(c);
+  if (c.slab) return c.team ? team_ctx_fast_poisson(c) : fail(c, "ekpnp_fast_poisson on a slab context without a transport: attach one (ekpnp_slab_attach_comm), use ekpnp_group_*, or drive ekpnp_poisson_stage1/2/3 yourself");
   return poisson_single(c);
+}
+
+extern "C" int ekpnp_invalidate_rhs(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  c.rhs_ready = false;
+  return EKPNP_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -489,7 +521,7 @@ extern "C" int ekpnp_pbe_end(ekpnp_ctx* ctx) {  // LBM.cu:107-108
 
 extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
-  if (c.slab) return fail(c, "ekpnp_initialization on a slab context: drive ekpnp_init_fields / ekpnp_pbe_* and the Poisson stages through the slab host");
+  if (c.slab) return c.team ? team_ctx_initialization(c) : fail(c, "ekpnp_initialization on a slab context without a transport: attach one, use ekpnp_group_*, or drive ekpnp_init_fields / ekpnp_pbe_* and the Poisson stages yourself");
   int rc = ekpnp_init_fields(ctx);
   if (rc == EKPNP_OK) rc = ekpnp_pbe_begin(ctx);
   for (int i = 0; rc == EKPNP_OK && i < c.p.pb_iterations; ++i) {  // LBM.cu:89-106
@@ -512,7 +544,7 @@ extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
 //    (NZ > ~180 at the default spacing); omega = min(PB_omega, 1.6/(1 + A)) is used.
 extern "C" int ekpnp_initialization_converged(ekpnp_ctx* ctx, double rel_tol, int max_sweeps, int* sweeps, double* residual) {
   NEEDCTX(ctx);
-  if (c.slab) return fail(c, "ekpnp_initialization_converged is implemented for single-slab contexts");
+  if (c.slab) return c.team ? team_ctx_initialization_converged(c, rel_tol, max_sweeps, sweeps, residual) : fail(c, "ekpnp_initialization_converged on a slab context without a transport: attach one or use ekpnp_group_*");
   if (max_sweeps < 0) return fail(c, "max_sweeps < 0");
   double omega = c.p.PB_omega;
   if (c.p.chargeinf > 0.0) {
@@ -616,7 +648,7 @@ static void finish_collide(Ctx& c) {
 extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
   NEEDCTX(ctx);
   (void)t;  // the reference passes t but never uses it (LBM.cu:483-1846)
-  if (c.slab) return fail(c, "slab context: use ekpnp_collide_boundary_planes/interior_planes + halo transport");
+  if (c.slab) return c.team ? team_ctx_stream_collide_save(c) : fail(c, "slab context without a transport: attach one, use ekpnp_group_*, or drive ekpnp_collide_boundary_planes/interior_planes + the halo exchange yourself");
   // (running the two wall planes on a second stream beside the bulk kernel was measured: no gain,
   // the bulk kernel already saturates HBM and merely stretches - profiles/r01_bench_after_tuning.log)
   const int zb = bulk_begin(c), ze = bulk_end(c);
@@ -695,7 +727,7 @@ static int capture_two_steps(ekpnp_ctx* ctx) {
 extern "C" int ekpnp_step(ekpnp_ctx* ctx, int nsteps) {
   NEEDCTX(ctx);
   if (nsteps < 0) return fail(c, "nsteps < 0");
-  if (c.slab) return fail(c, "slab context: drive the split calls through the slab host");
+  if (c.slab) return c.team ? team_ctx_step(c, nsteps) : fail(c, "slab context without a transport: attach one, use ekpnp_group_*, or drive the split calls yourself");
   int i = 0;
   if (c.streamed_state && nsteps > 0) {  // the first step after init_equilibrium does not pull
     int rc = one_step(ctx);
@@ -840,6 +872,7 @@ extern "C" int ekpnp_advance_time(ekpnp_ctx* ctx) {
 extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+  distrust_bound_rhs(c);
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
   FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.work, (hipfftDoubleComplex*)c.spec));

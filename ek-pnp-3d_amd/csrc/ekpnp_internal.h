@@ -74,9 +74,21 @@ struct KArgs {
   double rho0;
   // Poisson right-hand side written by the collide itself (poisson.cu:114-135 fused in)
   double* rhs;                 // [nzl][ny][nx] or null
-  double rhs_scale;            // -F/eps
-  double rhs_wall_lo, rhs_wall_hi;  // -voltage/dz^2 (plane 1), -voltage2/dz^2 (plane nz-2)
+  double eps;
+  double rhs_wall_lo, rhs_wall_hi;  // voltage/dz/dz (plane 1), voltage2/dz/dz (plane nz-2)
 };
+
+// Right-hand side of the Poisson equation on an interior plane, odd_extension's rows 1..NZ-2
+// (poisson.cu:121-135) in the reference's expression order: -F (c - cn)/eps, minus voltage/dz/dz on
+// the plane next to the lower plate, minus voltage2/dz/dz next to the upper one.  ONE function for
+// the collide kernel (which writes it from registers) and for k_poisson_rhs, so that
+// ekpnp_fast_poisson returns the same bits whichever of the two produced its input.
+__host__ __device__ inline double poisson_rhs_value(double F, double eps, double c, double cn, int z, int nz, double wall_lo, double wall_hi) {
+  double v = -F * (c - cn) / eps;
+  if (z == 1) v = v - wall_lo;
+  if (z == nz - 2) v = v - wall_hi;
+  return v;
+}
 
 struct PArgs {
   double* fld[EKPNP_NFIELDS];
@@ -88,7 +100,8 @@ struct PArgs {
   const double* vwall;         // {voltage, voltage2} in device memory
   int nx, ny, nz, nxh, nzl, z0;
   long long plane;
-  double F, eps, voltage, voltage2, inv_dz2, dx, dy, dz, inv_nxny;
+  double F, eps, voltage, voltage2, dx, dy, dz, inv_nxny;
+  double rhs_wall_lo, rhs_wall_hi;  // as in KArgs
 };
 
 struct Ctx;
@@ -109,7 +122,7 @@ void launch_ghost_wrap(Ctx&);
 void launch_halo_pack(Ctx&, int buffer);
 void launch_halo_unpack(Ctx&);
 // poisson.hip
-void build_cprime(Ctx&);
+int build_cprime(Ctx&);  // EKPNP_OK or a status with Ctx::err set
 void launch_poisson_rhs(Ctx&);
 void launch_tridiag(Ctx&);
 void launch_phi_efield(Ctx&);
@@ -158,6 +171,7 @@ struct Ctx {
   double* fld[EKPNP_NFIELDS] = {};
   bool fld_owned[EKPNP_NFIELDS] = {};
   void* fld_alloc[EKPNP_NFIELDS] = {};  // what hipMalloc returned for an owned field (fld[i] is skewed into it)
+  size_t fld_bytes[EKPNP_NFIELDS] = {}; // size of that allocation (skew pad included)
   double* work = nullptr;
   double2* spec = nullptr;
   double* cprime = nullptr;
@@ -181,6 +195,7 @@ struct Ctx {
   int graph_cur = -1;              // value of `cur` the graph was captured at
   bool graph_failed = false;       // capture is not possible here: stay eager
   hipfftHandle plan_fwd = 0, plan_inv = 0;
+  bool have_fwd = false, have_inv = false;  // each handle is destroyed on its own (a failing second plan must not leak the first)
   bool plans = false;
   double t = 0.0;
   size_t bytes = 0;
@@ -206,6 +221,7 @@ int team_ctx_initialization_converged(Ctx&, double rel_tol, int max_sweeps, int*
 int team_ctx_reduce(Ctx&, double* value, bool is_max);  // combine a per-slab diagnostic over the ranks
 int team_ctx_turns(Ctx&, int (*fn)(Ctx&, void*), void* arg);  // fn on every slab in rank order (file IO)
 void team_detach(Ctx&);  // called by ekpnp_destroy
+bool team_is_group(const Ctx&);  // the context is a member of an in-process ekpnp_group
 
 // io.hip pieces shared with slab_team.hip (a slab writes / reads its own planes of a whole-lattice file)
 struct TextIoArgs { const char* path; int append; double time; int first; int kind; };  // kind 0 Tecplot, 1 data_end

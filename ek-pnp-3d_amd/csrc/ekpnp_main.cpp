@@ -12,24 +12,37 @@
 // is a flag instead of scanf (main.cu:158-159); no system("pause") (main.cu:294); errors are
 // reported and returned, not exit()ed from inside the library.  Only the C ABI of
 // include/ekpnp.h is used: this file is also the worked example of INTEGRATION.md.
+//
+// --gpus N (N > 1) slab-decomposes the lattice along z over N GPUs of the node in THIS process
+// (ekpnp_group_*: RCCL ring + all-gather over xGMI on a high-priority comm stream per GPU, halo
+// exchange overlapped with the collision of the interior planes); same files, same formats.
+// --devices 0,0,1,1 places the slabs by hand (slabs sharing a device exchange by device copies).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/ekpnp.h"
 
-static int fail(ekpnp_ctx* ctx, const char* what, int rc) {
-  std::fprintf(stderr, "ekpnp_main: %s failed (%d): %s\n", what, rc, ekpnp_last_error(ctx));
-  if (ctx) ekpnp_destroy(ctx);
+// the lattice is either one context or a group of z slabs; the driver below does not care
+static ekpnp_ctx* ctx = nullptr;
+static ekpnp_group* grp = nullptr;
+
+static int fail(const char* what, int rc) {
+  std::fprintf(stderr, "ekpnp_main: %s failed (%d): %s\n", what, rc, grp ? ekpnp_group_last_error(grp) : ekpnp_last_error(ctx));
+  if (grp) ekpnp_group_destroy(grp);
+  else if (ctx) ekpnp_destroy(ctx);
   return 1;
 }
-#define CK(call)                              \
-  do {                                        \
-    int rc_ = (call);                         \
-    if (rc_ != EKPNP_OK) return fail(ctx, #call, rc_); \
+#define CK(call)                                   \
+  do {                                             \
+    int rc_ = (call);                              \
+    if (rc_ != EKPNP_OK) return fail(#call, rc_);  \
   } while (0)
+// one verb, two spellings
+#define RUN(verb, ...) (grp ? ekpnp_group_##verb(grp, ##__VA_ARGS__) : ekpnp_##verb(ctx, ##__VA_ARGS__))
 
 int main(int argc, char* argv[]) {
   // LBM.h:32-35,122-125
@@ -38,6 +51,8 @@ int main(int argc, char* argv[]) {
   int flag = 0;  // 1: read previous data (main.cu:161); 2: from the lossless data_end.bin
   int binary_state = 0;  // also write data_end.bin (ekpnp_save_state) at the end
   int lattices = 4;
+  int gpus = 1, transport = EKPNP_TRANSPORT_AUTO;
+  std::vector<int> devices;
   std::string out = ".";
   double exf = 0.0, uw = 0.0, chargeinf = -1.0, Ra = -1.0, TH = -1.0;
   for (int i = 1; i < argc; ++i) {
@@ -55,6 +70,16 @@ int main(int argc, char* argv[]) {
     else if ((v = val("--read-previous"))) flag = std::atoi(v);
     else if ((v = val("--binary-state"))) binary_state = std::atoi(v);
     else if ((v = val("--lattices"))) lattices = std::atoi(v);
+    else if ((v = val("--gpus"))) gpus = std::atoi(v);
+    else if ((v = val("--transport"))) transport = !std::strcmp(v, "rccl") ? EKPNP_TRANSPORT_RCCL : !std::strcmp(v, "copy") ? EKPNP_TRANSPORT_COPY : EKPNP_TRANSPORT_AUTO;
+    else if ((v = val("--devices"))) {
+      devices.clear();
+      for (const char* q = v; *q;) {
+        devices.push_back(std::atoi(q));
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+    }
     else if ((v = val("--out"))) out = v;
     else if ((v = val("--exf"))) exf = std::atof(v);
     else if ((v = val("--uw"))) uw = std::atof(v);
@@ -64,7 +89,7 @@ int main(int argc, char* argv[]) {
     else {
       std::fprintf(stderr,
                    "usage: ekpnp_main [--nx N --ny N --nz N] [--steps N] [--nsave N] [--print-current N] [--read-previous 0|1|2]\n"
-                   "                  [--binary-state 0|1]\n"
+                   "                  [--binary-state 0|1] [--gpus N [--transport auto|rccl|copy] [--devices d0,d1,...]]\n"
                    "                  [--lattices 1|3|4] [--exf F --uw U --chargeinf C --Ra R --TH T] [--out DIR]\n");
       return 2;
     }
@@ -72,9 +97,10 @@ int main(int argc, char* argv[]) {
   if (nsave == 0) nsave = nsteps / 2 ? nsteps / 2 : 1;  // LBM.h:123
   if (print_current == 0) print_current = 1;
 
-  ekpnp_ctx* ctx = nullptr;
+  if (!devices.empty()) gpus = (int)devices.size();
+  if (gpus < 1) gpus = 1;
   ekpnp_params P;
-  if (ekpnp_default_params(&P, nx, ny, nz) != EKPNP_OK) return fail(nullptr, "ekpnp_default_params", 1);
+  if (ekpnp_default_params(&P, nx, ny, nz) != EKPNP_OK) return fail("ekpnp_default_params", 1);
   if (nx == 50 && ny == 8 && nz == 51) { P.Lx = 0.5e-6; P.Ly = 0.08e-6; P.Lz = 0.5e-6; }  // literals of LBM.h:40-42
   P.n_lattices = lattices;
   P.exf = exf; P.uw = uw;  // main.cu:30-31
@@ -94,50 +120,55 @@ int main(int argc, char* argv[]) {
   std::printf("    message every: %u\n", nsave);
   std::printf("\n");
 
-  {
+  if (gpus > 1 || !devices.empty()) {
+    int rc = ekpnp_group_create(&P, gpus, devices.empty() ? nullptr : devices.data(), transport, &grp);
+    if (rc != EKPNP_OK) return fail("ekpnp_group_create", rc);
+  } else {
     int rc = ekpnp_create(&P, &ctx);
-    if (rc != EKPNP_OK) return fail(nullptr, "ekpnp_create", rc);
+    if (rc != EKPNP_OK) return fail("ekpnp_create", rc);
   }
   std::printf("HIP information\n");
-  std::printf("      device memory held by the solver: %.1f MiB\n\n", (double)ekpnp_device_bytes(ctx) / (1024.0 * 1024.0));
+  if (grp)
+    std::printf("      z slabs: %d, halo transport: %s\n", ekpnp_group_size(grp), ekpnp_group_transport(grp) == EKPNP_TRANSPORT_RCCL ? "RCCL" : "device copies");
+  std::printf("      device memory held by the solver: %.1f MiB\n\n", (double)(grp ? ekpnp_group_device_bytes(grp) : ekpnp_device_bytes(ctx)) / (1024.0 * 1024.0));
 
   const std::string f_data = out + "/data.dat", f_umax = out + "/umax.dat", f_end = out + "/data_end.dat";
   const std::string f_bin = out + "/data_end.bin";
   double t = 0.0;
   if (flag == 1) {  // main.cu:161-164
     std::printf("Reading previous data...\n");
-    CK(ekpnp_read_data(ctx, f_end.c_str(), &t));
+    CK(RUN(read_data, f_end.c_str(), &t));
   } else if (flag == 2) {  // the same restart from the lossless file
     std::printf("Reading previous data (binary)...\n");
-    CK(ekpnp_read_state(ctx, f_bin.c_str(), &t));
+    CK(RUN(read_state, f_bin.c_str(), &t));
   } else {  // main.cu:165-171
     std::printf("Initializing...\n");
-    CK(ekpnp_initialization(ctx));
+    CK(RUN(initialization));
     t = 0.0;
   }
-  CK(ekpnp_set_time(ctx, t));
-  CK(ekpnp_init_equilibrium(ctx));                             // main.cu:174
-  CK(ekpnp_save_data_tecplot(ctx, f_data.c_str(), 0, t, 1));   // main.cu:178-179 ("wb+")
+  CK(RUN(set_time, t));
+  CK(RUN(init_equilibrium));                             // main.cu:174
+  CK(RUN(save_data_tecplot, f_data.c_str(), 0, t, 1));   // main.cu:178-179 ("wb+")
   { FILE* f = std::fopen(f_umax.c_str(), "wb"); if (f) std::fclose(f); }  // main.cu:180
 
-  CK(ekpnp_synchronize(ctx));
+  CK(RUN(synchronize));
   const auto begin = std::chrono::steady_clock::now();  // main.cu:185-186
   for (unsigned i = 0; i < nsteps; i++) {               // main.cu:189-224
-    CK(ekpnp_stream_collide_save(ctx, t));
-    CK(ekpnp_fast_poisson(ctx));
+    CK(RUN(stream_collide_save, t));
+    CK(RUN(fast_poisson));
     t = t + P.dt;
     if (i % nsave == 1) {
-      CK(ekpnp_save_data_tecplot(ctx, f_data.c_str(), 1, t, 1));
+      CK(RUN(save_data_tecplot, f_data.c_str(), 1, t, 1));
       std::printf("Iteration: %u, physical time: %g.\n", i, t);
     }
     if (i % print_current == 1) {
       double I = 0.0;
-      CK(ekpnp_current(ctx, &I));  // reduced on the device (main.cu:212-215 copies 3 fields to the host)
+      CK(RUN(current, &I));  // reduced on the device (main.cu:212-215 copies 3 fields to the host)
       std::printf("Iteration: %u, physical time: %g, Current = %g\n", i, t, I);
-      CK(ekpnp_record_umax(ctx, f_umax.c_str(), 1, t));
+      CK(RUN(record_umax, f_umax.c_str(), 1, t));
     }
   }
-  CK(ekpnp_synchronize(ctx));
+  CK(RUN(synchronize));
   const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count();
 
   // main.cu:241-251
@@ -147,9 +178,9 @@ int main(int argc, char* argv[]) {
   std::printf("           clock runtime: %.3f (s)\n", runtime);
   std::printf("                   speed: %.2f (Mlups)\n", nodes_updated / (1e6 * runtime));
 
-  CK(ekpnp_save_data_tecplot(ctx, f_data.c_str(), 1, t, 1));  // main.cu:253
-  CK(ekpnp_save_data_end(ctx, f_end.c_str(), 0, t));          // main.cu:256-257
-  if (binary_state) CK(ekpnp_save_state(ctx, f_bin.c_str(), t));
-  CK(ekpnp_destroy(ctx));                                     // main.cu:264-290
+  CK(RUN(save_data_tecplot, f_data.c_str(), 1, t, 1));  // main.cu:253
+  CK(RUN(save_data_end, f_end.c_str(), 0, t));          // main.cu:256-257
+  if (binary_state) CK(RUN(save_state, f_bin.c_str(), t));
+  CK(grp ? ekpnp_group_destroy(grp) : ekpnp_destroy(ctx));    // main.cu:264-290
   return 0;
 }

@@ -43,16 +43,18 @@ extern "C" int ekpnp_current(ekpnp_ctx* ctx, double* I) {
   NEEDCTX(ctx);
   if (!I) return fail(c, "NULL pointer");
   *I = 0.0;
-  if (c.z0 + c.nzl != c.p.nz) return EKPNP_OK;  // this slab does not hold the upper plate: contributes 0
-  if (c.nzl < 3) return fail(c, "the upper slab needs 3 planes for the wall extrapolation");
-  int rc = need_scratch(c);
-  if (rc) return rc;
-  launch_current(c, c.diag);
-  double s = 0.0;
-  HIPCHK(c, hipMemcpyAsync(&s, c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(c, hipStreamSynchronize(c.stream));
-  *I = s * c.p.K * c.p.dz * c.p.dz;  // LBM.cu:2708
-  return EKPNP_OK;
+  const bool combine = c.team && !team_is_group(c);  // attached transport: every rank returns the lattice's value
+  if (c.z0 + c.nzl == c.p.nz) {  // a slab that does not hold the upper plate contributes 0
+    if (c.nzl < 3) return fail(c, "the upper slab needs 3 planes for the wall extrapolation");
+    int rc = need_scratch(c);
+    if (rc) return rc;
+    launch_current(c, c.diag);
+    double s = 0.0;
+    HIPCHK(c, hipMemcpyAsync(&s, c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(c, hipStreamSynchronize(c.stream));
+    *I = s * c.p.K * c.p.dz * c.p.dz;  // LBM.cu:2708
+  }
+  return combine ? team_ctx_reduce(c, I, false) : EKPNP_OK;
 }
 
 extern "C" int ekpnp_umax(ekpnp_ctx* ctx, double* umax) {
@@ -65,7 +67,7 @@ extern "C" int ekpnp_umax(ekpnp_ctx* ctx, double* umax) {
   HIPCHK(c, hipMemcpyAsync(&s, c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(c, hipStreamSynchronize(c.stream));
   *umax = s;
-  return EKPNP_OK;
+  return (c.team && !team_is_group(c)) ? team_ctx_reduce(c, umax, true) : EKPNP_OK;
 }
 
 extern "C" int ekpnp_record_umax(ekpnp_ctx* ctx, const char* path, int append, double time) {
@@ -74,6 +76,7 @@ extern "C" int ekpnp_record_umax(ekpnp_ctx* ctx, const char* path, int append, d
   double um = 0.0;
   int rc = ekpnp_umax(ctx, &um);
   if (rc) return rc;
+  if (c.team && !team_is_group(c) && c.rank != 0) return EKPNP_OK;  // one line per call: rank 0 writes the combined value
   FILE* f = std::fopen(path, append ? "ab" : "wb");
   if (!f) return fail(c, "cannot open umax file");
   std::fprintf(f, "%10.6f %10.6f\n", time, um);  // LBM.cu:2748
@@ -81,76 +84,72 @@ extern "C" int ekpnp_record_umax(ekpnp_ctx* ctx, const char* path, int append, d
   return EKPNP_OK;
 }
 
-// host copies of the 11 fields, with the reference's wall extrapolation of rho, c, cn, u
+// host copies of the 11 fields of this context's planes, with the reference's wall extrapolation
+// of rho, c, cn, u on the plates it holds (LBM.cu:2527-2542 / 2596-2611); planes 0..2 and
+// NZ-3..NZ-1 always lie inside one slab (a slab has at least 4 planes)
 static int fetch_fields(Ctx& c, std::vector<std::vector<double>>& h, bool extrapolate) {
-  if (c.nranks != 1) return fail(c, "file IO is implemented for single-slab contexts");
   HIPCHK(c, hipStreamSynchronize(c.stream));
   h.assign(EKPNP_NFIELDS, std::vector<double>(c.nloc));
   for (int i = 0; i < EKPNP_NFIELDS; ++i) HIPCHK(c, hipMemcpy(h[i].data(), c.fld[i], c.nloc * sizeof(double), hipMemcpyDeviceToHost));
-  if (extrapolate) {  // LBM.cu:2527-2542 / 2596-2611
-    const size_t pl = c.plane, nz = c.p.nz;
+  if (extrapolate) {
+    const size_t pl = c.plane, nzl = c.nzl;
+    const bool lower = c.z0 == 0, upper = c.z0 + c.nzl == c.p.nz;
+    if ((lower || upper) && nzl < 3) return fail(c, "a slab holding a plate needs 3 planes for the wall extrapolation");
     const int ids[6] = {EKPNP_RHO, EKPNP_C, EKPNP_CN, EKPNP_UX, EKPNP_UY, EKPNP_UZ};
     for (int k = 0; k < 6; ++k) {
       double* a = h[ids[k]].data();
       for (size_t i = 0; i < pl; ++i) {
-        a[i] = 2.0 * a[pl + i] - a[2 * pl + i];
-        a[(nz - 1) * pl + i] = 2.0 * a[(nz - 2) * pl + i] - a[(nz - 3) * pl + i];
+        if (lower) a[i] = 2.0 * a[pl + i] - a[2 * pl + i];
+        if (upper) a[(nzl - 1) * pl + i] = 2.0 * a[(nzl - 2) * pl + i] - a[(nzl - 3) * pl + i];
       }
     }
   }
   return EKPNP_OK;
 }
 
-extern "C" int ekpnp_save_data_tecplot(ekpnp_ctx* ctx, const char* path, int append, double time, int first) {
-  NEEDCTX(ctx);
-  if (!path) return fail(c, "NULL path");
+namespace ekpnp {
+// This context's planes of a whole-lattice text file: kind 0 = Tecplot POINT zone (header lines
+// when it holds plane 0), kind 1 = the 12-column restart file.  Slabs append in z order.
+int io_write_text_part(Ctx& c, const TextIoArgs& a) {
   std::vector<std::vector<double>> h;
   int rc = fetch_fields(c, h, true);
   if (rc) return rc;
-  FILE* f = std::fopen(path, append ? "ab" : "wb");
-  if (!f) return fail(c, "cannot open Tecplot file");
-  if (first)  // LBM.cu:2546-2548
-    std::fprintf(f, "%s\n", "VARIABLES=\"x\",\"y\",\"z\",\"u\",\"v\",\"w\",\"p\",\"charge\",\"neg charge\",\"phi\",\"Ex\",\"Ey\",\"Ez\",\"Temperature\"");
-  std::fprintf(f, "\n");
-  std::fprintf(f, "ZONE T=\"t=%g\", F=POINT, I = %d, J = %d, K = %d\n", time, c.p.nx, c.p.ny, c.p.nz);  // LBM.cu:2551
+  FILE* f = std::fopen(a.path, a.append ? "ab" : "wb");
+  if (!f) return fail(c, a.kind == 0 ? "cannot open Tecplot file" : "cannot open restart file");
+  if (a.kind == 0 && c.z0 == 0) {
+    if (a.first)  // LBM.cu:2546-2548
+      std::fprintf(f, "%s\n", "VARIABLES=\"x\",\"y\",\"z\",\"u\",\"v\",\"w\",\"p\",\"charge\",\"neg charge\",\"phi\",\"Ex\",\"Ey\",\"Ez\",\"Temperature\"");
+    std::fprintf(f, "\n");
+    std::fprintf(f, "ZONE T=\"t=%g\", F=POINT, I = %d, J = %d, K = %d\n", a.time, c.p.nx, c.p.ny, c.p.nz);  // LBM.cu:2551
+  }
   const double dx = c.p.dx, dy = c.p.dy, dz = c.p.dz;
   size_t i = 0;
-  for (unsigned z = 0; z < (unsigned)c.p.nz; ++z)
+  for (unsigned zl = 0; zl < (unsigned)c.nzl; ++zl)
     for (unsigned y = 0; y < (unsigned)c.p.ny; ++y)
-      for (unsigned x = 0; x < (unsigned)c.p.nx; ++x, ++i)
-        std::fprintf(f, "%g %g %g %g %g %g %g %g %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f\n", dx * x, dy * y, dz * z, h[EKPNP_UX][i],
-                     h[EKPNP_UY][i], h[EKPNP_UZ][i], h[EKPNP_RHO][i], h[EKPNP_C][i], h[EKPNP_CN][i], h[EKPNP_PHI][i], h[EKPNP_EX][i],
-                     h[EKPNP_EY][i], h[EKPNP_EZ][i], h[EKPNP_T][i]);  // LBM.cu:2559-2561
+      for (unsigned x = 0; x < (unsigned)c.p.nx; ++x, ++i) {
+        if (a.kind == 0)  // LBM.cu:2559-2561
+          std::fprintf(f, "%g %g %g %g %g %g %g %g %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f\n", dx * x, dy * y, dz * (zl + (unsigned)c.z0),
+                       h[EKPNP_UX][i], h[EKPNP_UY][i], h[EKPNP_UZ][i], h[EKPNP_RHO][i], h[EKPNP_C][i], h[EKPNP_CN][i], h[EKPNP_PHI][i],
+                       h[EKPNP_EX][i], h[EKPNP_EY][i], h[EKPNP_EZ][i], h[EKPNP_T][i]);
+        else  // LBM.cu:2619-2622
+          std::fprintf(f, "%10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f\n", a.time, h[EKPNP_UX][i],
+                       h[EKPNP_UY][i], h[EKPNP_UZ][i], h[EKPNP_RHO][i], h[EKPNP_C][i], h[EKPNP_CN][i], h[EKPNP_PHI][i], h[EKPNP_EX][i],
+                       h[EKPNP_EY][i], h[EKPNP_EZ][i], h[EKPNP_T][i]);
+      }
   const bool bad = std::ferror(f) != 0;
-  std::fclose(f);
-  return bad ? fail(c, "write error on Tecplot file") : EKPNP_OK;
+  return (std::fclose(f) != 0 || bad) ? fail(c, "write error on output file") : EKPNP_OK;
 }
 
-extern "C" int ekpnp_save_data_end(ekpnp_ctx* ctx, const char* path, int append, double time) {
-  NEEDCTX(ctx);
-  if (!path) return fail(c, "NULL path");
-  std::vector<std::vector<double>> h;
-  int rc = fetch_fields(c, h, true);
-  if (rc) return rc;
-  FILE* f = std::fopen(path, append ? "ab" : "wb");
-  if (!f) return fail(c, "cannot open restart file");
-  for (size_t i = 0; i < c.nloc; ++i)  // LBM.cu:2619-2622
-    std::fprintf(f, "%10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f %10.6f\n", time, h[EKPNP_UX][i],
-                 h[EKPNP_UY][i], h[EKPNP_UZ][i], h[EKPNP_RHO][i], h[EKPNP_C][i], h[EKPNP_CN][i], h[EKPNP_PHI][i], h[EKPNP_EX][i],
-                 h[EKPNP_EY][i], h[EKPNP_EZ][i], h[EKPNP_T][i]);
-  const bool bad = std::ferror(f) != 0;
-  std::fclose(f);
-  return bad ? fail(c, "write error on restart file") : EKPNP_OK;
-}
-
-extern "C" int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time) {
-  NEEDCTX(ctx);
-  if (!path || !time) return fail(c, "NULL pointer");
-  if (c.nranks != 1) return fail(c, "file IO is implemented for single-slab contexts");
+// This context's planes out of a save_data_end file of the whole lattice (LBM.cu:2645-2657)
+int io_read_data_part(Ctx& c, const char* path, double* time) {
   FILE* f = std::fopen(path, "r");
   if (!f) return fail(c, "cannot open restart file");
   std::vector<std::vector<double>> h(EKPNP_NFIELDS, std::vector<double>(c.nloc));
   bool ok = true;
+  double skip[12];
+  for (size_t i = 0, n = (size_t)c.z0 * c.plane; ok && i < n; ++i)  // the planes below this slab
+    ok = std::fscanf(f, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf", skip, skip + 1, skip + 2, skip + 3, skip + 4, skip + 5, skip + 6,
+                     skip + 7, skip + 8, skip + 9, skip + 10, skip + 11) == 12;
   for (size_t i = 0; ok && i < c.nloc; ++i)  // LBM.cu:2652-2655
     ok = std::fscanf(f, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf", time, &h[EKPNP_UX][i], &h[EKPNP_UY][i], &h[EKPNP_UZ][i],
                      &h[EKPNP_RHO][i], &h[EKPNP_C][i], &h[EKPNP_CN][i], &h[EKPNP_PHI][i], &h[EKPNP_EX][i], &h[EKPNP_EY][i], &h[EKPNP_EZ][i],
@@ -162,6 +161,47 @@ extern "C" int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time) {
   c.t = *time;
   c.rhs_ready = false;
   return EKPNP_OK;
+}
+}  // namespace ekpnp
+
+namespace {
+int write_part_turn(Ctx& c, void* arg) {
+  TextIoArgs a = *static_cast<TextIoArgs*>(arg);
+  if (c.rank != 0) a.append = 1;
+  return io_write_text_part(c, a);
+}
+struct ReadTurn { const char* path; double* time; };
+int read_part_turn(Ctx& c, void* arg) {
+  ReadTurn* a = static_cast<ReadTurn*>(arg);
+  return io_read_data_part(c, a->path, a->time);
+}
+const char* const kNoTransport = "file IO on a slab context without a transport: attach one (ekpnp_slab_attach_comm) or use ekpnp_group_*";
+}  // namespace
+
+extern "C" int ekpnp_save_data_tecplot(ekpnp_ctx* ctx, const char* path, int append, double time, int first) {
+  NEEDCTX(ctx);
+  if (!path) return fail(c, "NULL path");
+  TextIoArgs a{path, append, time, first, 0};
+  if (c.slab && c.nranks > 1) return c.team ? team_ctx_turns(c, write_part_turn, &a) : fail(c, kNoTransport);
+  return io_write_text_part(c, a);
+}
+
+extern "C" int ekpnp_save_data_end(ekpnp_ctx* ctx, const char* path, int append, double time) {
+  NEEDCTX(ctx);
+  if (!path) return fail(c, "NULL path");
+  TextIoArgs a{path, append, time, 0, 1};
+  if (c.slab && c.nranks > 1) return c.team ? team_ctx_turns(c, write_part_turn, &a) : fail(c, kNoTransport);
+  return io_write_text_part(c, a);
+}
+
+extern "C" int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time) {
+  NEEDCTX(ctx);
+  if (!path || !time) return fail(c, "NULL pointer");
+  if (c.slab && c.nranks > 1) {
+    ReadTurn a{path, time};
+    return c.team ? team_ctx_turns(c, read_part_turn, &a) : fail(c, kNoTransport);
+  }
+  return io_read_data_part(c, path, time);
 }
 
 // ---- lossless binary state (no reference counterpart beyond the save_data_end / read_data pair) ----

@@ -243,11 +243,7 @@ __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(
     const double m = lat == 1 ? c : lat == 2 ? cn : T;
     if (act) a.fld[lat == 1 ? EKPNP_C : lat == 2 ? EKPNP_CN : EKPNP_T][sidx] = m;  // LBM.cu:811-813
     if (lat == 1 && act && a.rhs) {  // odd_extension's interior rows, poisson.cu:121-135, from registers
-      const int z = a.z0 + zl;
-      double g = a.rhs_scale * (c - cn);
-      if (z == 1) g = g + a.rhs_wall_lo;
-      if (z == a.nz - 2) g = g + a.rhs_wall_hi;
-      a.rhs[sidx] = g;
+      a.rhs[sidx] = poisson_rhs_value(a.F, a.eps, c, cn, a.z0 + zl, a.nz, a.rhs_wall_lo, a.rhs_wall_hi);
     }
     const double k = a.mob[lat];
     collide_scalar(a, f, m, ux + k * Ex, uy + k * Ey, uz + k * Ez, a.wp[lat], a.wm[lat], store);

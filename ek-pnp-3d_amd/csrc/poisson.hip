@@ -25,11 +25,7 @@ __global__ void k_poisson_rhs(PArgs a) {
   if (i >= n) return;
   const int z = a.z0 + (int)(i / a.plane);
   double v = 0.0;
-  if (z > 0 && z < a.nz - 1) {
-    v = -a.F * (a.fld[EKPNP_C][i] - a.fld[EKPNP_CN][i]) / a.eps;
-    if (z == 1) v = v - a.voltage * a.inv_dz2;
-    if (z == a.nz - 2) v = v - a.voltage2 * a.inv_dz2;
-  }
+  if (z > 0 && z < a.nz - 1) v = poisson_rhs_value(a.F, a.eps, a.fld[EKPNP_C][i], a.fld[EKPNP_CN][i], z, a.nz, a.rhs_wall_lo, a.rhs_wall_hi);
   a.work[i] = v;
 }
 
@@ -479,28 +475,37 @@ __global__ void k_phi_halo_pack(PArgs a, double* __restrict__ send_dn, double* _
   send_up[i] = zt == a.nz - 1 ? a.voltage2 : a.work[(long long)(a.nzl - 1) * a.plane + i] * a.inv_nxny;
 }
 
-void build_cprime(Ctx& c) {
+int build_cprime(Ctx& c) {
   const int nm = c.p.ny * c.nxh;
+  auto hipfail = [&](const char* what, hipError_t e) {
+    c.err = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? EKPNP_ERR_NOMEM : EKPNP_ERR_HIP;
+  };
   // single context: rows 1..nz-2 of the global system; slab: rows 1..nzl of a local block
   const int rows_nz = !c.slab ? c.p.nz : c.nzl + 2;
   hipLaunchKernelGGL(k_build_cprime, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.p.nx, c.p.ny, rows_nz, c.nxh, c.p.Lx,
                      c.p.Ly, c.p.dz);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hipfail("k_build_cprime launch", e);
   if (c.slab) {
     const bool edge_rank = (c.rank == 0 || c.rank == c.nranks - 1);
     hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.slab_m, nm, c.slab_u,
                        edge_rank ? c.u1um[0] : c.u1um[1], c.slab_w);
+    if ((e = hipGetLastError()) != hipSuccess) return hipfail("k_slab_unit_response launch", e);
     // (u_1, u_m) of the other slab type, through a scratch vector (set-up only)
     const int m_other = edge_rank ? c.nzl : c.nzl - 1;
     double* tmp = nullptr;
-    if (hipMalloc((void**)&tmp, (size_t)m_other * nm * sizeof(double)) == hipSuccess) {
-      hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, m_other, nm, tmp,
-                         edge_rank ? c.u1um[1] : c.u1um[0], (double*)nullptr);
-      (void)hipStreamSynchronize(c.stream);
-      (void)hipFree(tmp);
-    } else {
-      c.err = "scratch allocation for the slab unit response failed";
-    }
+    if ((e = hipMalloc((void**)&tmp, (size_t)m_other * nm * sizeof(double))) != hipSuccess) return hipfail("scratch allocation for the slab unit response", e);
+    hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, m_other, nm, tmp,
+                       edge_rank ? c.u1um[1] : c.u1um[0], (double*)nullptr);
+    e = hipGetLastError();
+    const hipError_t es = hipStreamSynchronize(c.stream);
+    const hipError_t ef = hipFree(tmp);
+    if (e != hipSuccess) return hipfail("k_slab_unit_response launch", e);
+    if (es != hipSuccess) return hipfail("slab unit response", es);
+    if (ef != hipSuccess) return hipfail("hipFree of the unit-response scratch", ef);
   }
+  return EKPNP_OK;
 }
 
 void launch_slab_thomas_local(Ctx& c) {

@@ -518,6 +518,8 @@ int team_ctx_reduce(Ctx& c, double* value, bool is_max) {
 }
 int team_ctx_turns(Ctx& c, int (*fn)(Ctx&, void*), void* arg) { OWN_TEAM(c); return lift(c, *T, team_turns(*T, fn, arg)); }
 
+bool team_is_group(const Ctx& c) { return c.team && c.team->group; }
+
 void team_detach(Ctx& c) {
   if (!c.team || c.team->group) return;  // a group releases its own team (ekpnp_group_destroy)
   Team* T = c.team;

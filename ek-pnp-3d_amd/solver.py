@@ -103,6 +103,7 @@ def load_library():
         "ekpnp_init_equilibrium": (i32, [ctx]),
         "ekpnp_stream_collide_save": (i32, [ctx, dbl]),
         "ekpnp_fast_poisson": (i32, [ctx]),
+        "ekpnp_invalidate_rhs": (i32, [ctx]),
         "ekpnp_step": (i32, [ctx, i32]),
         "ekpnp_get_time": (i32, [ctx, pd]),
         "ekpnp_set_time": (i32, [ctx, dbl]),
@@ -139,6 +140,35 @@ def load_library():
         "ekpnp_read_state": (i32, [ctx, C.c_char_p, pd]),
         "ekpnp_compute_parameters": (i32, [C.POINTER(Params), pd, pd, pd, pd, pd]),
         "ekpnp_save_scalar": (i32, [ctx, C.c_char_p, i32, C.c_uint, C.c_uint]),
+        # the library's own halo transport (RCCL / peer copies)
+        "ekpnp_comm_unique_id": (i32, [C.c_void_p]),
+        "ekpnp_slab_attach_comm": (i32, [ctx, C.c_void_p]),
+        "ekpnp_group_create": (i32, [C.POINTER(Params), i32, C.POINTER(i32), i32, C.POINTER(ctx)]),
+        "ekpnp_group_destroy": (i32, [ctx]),
+        "ekpnp_group_last_error": (C.c_char_p, [ctx]),
+        "ekpnp_group_size": (i32, [ctx]),
+        "ekpnp_group_transport": (i32, [ctx]),
+        "ekpnp_group_context": (i32, [ctx, i32, C.POINTER(ctx)]),
+        "ekpnp_group_device_bytes": (sz, [ctx]),
+        "ekpnp_group_synchronize": (i32, [ctx]),
+        "ekpnp_group_set_field": (i32, [ctx, i32, C.c_void_p]),
+        "ekpnp_group_get_field": (i32, [ctx, i32, C.c_void_p]),
+        "ekpnp_group_initialization": (i32, [ctx]),
+        "ekpnp_group_initialization_converged": (i32, [ctx, dbl, i32, C.POINTER(i32), pd]),
+        "ekpnp_group_init_equilibrium": (i32, [ctx]),
+        "ekpnp_group_stream_collide_save": (i32, [ctx, dbl]),
+        "ekpnp_group_fast_poisson": (i32, [ctx]),
+        "ekpnp_group_step": (i32, [ctx, i32]),
+        "ekpnp_group_get_time": (i32, [ctx, pd]),
+        "ekpnp_group_set_time": (i32, [ctx, dbl]),
+        "ekpnp_group_current": (i32, [ctx, pd]),
+        "ekpnp_group_umax": (i32, [ctx, pd]),
+        "ekpnp_group_record_umax": (i32, [ctx, C.c_char_p, i32, dbl]),
+        "ekpnp_group_save_data_tecplot": (i32, [ctx, C.c_char_p, i32, dbl, i32]),
+        "ekpnp_group_save_data_end": (i32, [ctx, C.c_char_p, i32, dbl]),
+        "ekpnp_group_read_data": (i32, [ctx, C.c_char_p, pd]),
+        "ekpnp_group_save_state": (i32, [ctx, C.c_char_p, dbl]),
+        "ekpnp_group_read_state": (i32, [ctx, C.c_char_p, pd]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it
@@ -163,6 +193,19 @@ def compute_parameters(p: Params) -> dict:
     if rc:
         raise EkpnpError(f"ekpnp_compute_parameters -> {rc}")
     return dict(zip(("T", "M", "C", "Fe", "Pr"), (x.value for x in v)))
+
+
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_COPY = 0, 1, 2
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: made by ONE rank, handed to all (ekpnp_comm_unique_id)."""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    rc = load_library().ekpnp_comm_unique_id(buf)
+    if rc:
+        raise EkpnpError(f"ekpnp_comm_unique_id -> {rc} (librccl.so.1 not loadable?)")
+    return buf.raw
 
 
 class Solver:
@@ -324,6 +367,17 @@ class Solver:
         self._ck(self._L.ekpnp_read_state(self._h, os.fsencode(path), C.byref(t)))
         return t.value
 
+    def invalidate_rhs(self):
+        self._ck(self._L.ekpnp_invalidate_rhs(self._h))
+
+    def attach_comm(self, unique_id: bytes):
+        """Collective over the ranks (ncclCommInitRank): from here on the reference's verbs
+        (initialization, stream_collide_save, fast_Poisson, step, current, umax, the writers)
+        work on this slab context, the library moving the halos over RCCL itself."""
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        self._ck(self._L.ekpnp_slab_attach_comm(self._h, C.c_char_p(unique_id)))
+
     # -- z-slab pieces (driven by slab.py) ---------------------------------------------------
     def call(self, name: str):
         """Invoke a parameterless `int ekpnp_<name>(ctx)` entry point."""
@@ -344,3 +398,140 @@ class Solver:
         n, ms, nodes = C.c_int(), C.c_double(), C.c_int64()
         self._ck(self._L.ekpnp_kernel_timing_get(self._h, C.byref(n), C.byref(ms), C.byref(nodes)))
         return n.value, ms.value, nodes.value
+
+
+class Group:
+    """nslabs z slabs driven by ONE process (ekpnp_group_*): slab i on HIP device devices[i]
+    (default: i modulo the device count; devices may repeat, then the halos move by device copies).
+    Same method names as Solver; fields are whole-lattice arrays [NZ][NY][NX]."""
+
+    def __init__(self, params: Params, nslabs: int, devices=None, transport: int = TRANSPORT_AUTO):
+        self._L = load_library()
+        self.p = params.copy()
+        self._g = C.c_void_p()
+        dev = None
+        if devices is not None:
+            if len(devices) != nslabs:
+                raise ValueError("one device per slab")
+            dev = (C.c_int * nslabs)(*devices)
+        rc = self._L.ekpnp_group_create(C.byref(self.p), int(nslabs), dev, int(transport), C.byref(self._g))
+        if rc:
+            msg = self._L.ekpnp_group_last_error(None).decode()
+            self._g = C.c_void_p()
+            raise EkpnpError(f"ekpnp_group_create failed ({rc}): {msg}")
+        self.n = nslabs
+        self.shape = (self.p.nz, self.p.ny, self.p.nx)
+        self.transport = int(self._L.ekpnp_group_transport(self._g))
+
+    def _ck(self, rc: int):
+        if rc:
+            raise EkpnpError(f"status {rc}: {self._L.ekpnp_group_last_error(self._g).decode()}")
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._L.ekpnp_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def slab_handle(self, i: int):
+        h = C.c_void_p()
+        self._ck(self._L.ekpnp_group_context(self._g, int(i), C.byref(h)))
+        return h
+
+    def slab_extent(self, i: int):
+        z0, nzl = C.c_int(), C.c_int()
+        rc = self._L.ekpnp_local_extent(self.slab_handle(i), C.byref(z0), C.byref(nzl))
+        if rc:
+            raise EkpnpError(f"ekpnp_local_extent -> {rc}")
+        return z0.value, nzl.value
+
+    def device_bytes(self) -> int:
+        return int(self._L.ekpnp_group_device_bytes(self._g))
+
+    def synchronize(self):
+        self._ck(self._L.ekpnp_group_synchronize(self._g))
+
+    def get_field(self, name: str) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float64)
+        self._ck(self._L.ekpnp_group_get_field(self._g, FIELD_ID[name], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_field(self, name: str, value):
+        a = np.ascontiguousarray(value, dtype=np.float64).reshape(self.shape)
+        self._ck(self._L.ekpnp_group_set_field(self._g, FIELD_ID[name], a.ctypes.data_as(C.c_void_p)))
+
+    def fields(self) -> dict:
+        return {n: self.get_field(n) for n in FIELDS}
+
+    def set_fields(self, d: dict):
+        for n, v in d.items():
+            self.set_field(n, v)
+
+    def initialization(self):
+        self._ck(self._L.ekpnp_group_initialization(self._g))
+
+    def initialization_converged(self, rel_tol: float = 1e-10, max_sweeps: int = 100000):
+        n, r = C.c_int(), C.c_double()
+        self._ck(self._L.ekpnp_group_initialization_converged(self._g, float(rel_tol), int(max_sweeps), C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def init_equilibrium(self):
+        self._ck(self._L.ekpnp_group_init_equilibrium(self._g))
+
+    def stream_collide_save(self, t: float = 0.0):
+        self._ck(self._L.ekpnp_group_stream_collide_save(self._g, float(t)))
+
+    def fast_Poisson(self):
+        self._ck(self._L.ekpnp_group_fast_poisson(self._g))
+
+    def step(self, n: int = 1):
+        self._ck(self._L.ekpnp_group_step(self._g, int(n)))
+
+    @property
+    def t(self) -> float:
+        v = C.c_double()
+        self._ck(self._L.ekpnp_group_get_time(self._g, C.byref(v)))
+        return v.value
+
+    def current(self) -> float:
+        v = C.c_double()
+        self._ck(self._L.ekpnp_group_current(self._g, C.byref(v)))
+        return v.value
+
+    def umax(self) -> float:
+        v = C.c_double()
+        self._ck(self._L.ekpnp_group_umax(self._g, C.byref(v)))
+        return v.value
+
+    def record_umax(self, path: str, time: float, append: bool = True):
+        self._ck(self._L.ekpnp_group_record_umax(self._g, os.fsencode(path), int(append), float(time)))
+
+    def save_data_tecplot(self, path: str, time: float, first: bool = True, append: bool = False):
+        self._ck(self._L.ekpnp_group_save_data_tecplot(self._g, os.fsencode(path), int(append), float(time), int(first)))
+
+    def save_data_end(self, path: str, time: float, append: bool = False):
+        self._ck(self._L.ekpnp_group_save_data_end(self._g, os.fsencode(path), int(append), float(time)))
+
+    def read_data(self, path: str) -> float:
+        t = C.c_double()
+        self._ck(self._L.ekpnp_group_read_data(self._g, os.fsencode(path), C.byref(t)))
+        return t.value
+
+    def save_state(self, path: str, time: float = 0.0):
+        self._ck(self._L.ekpnp_group_save_state(self._g, os.fsencode(path), float(time)))
+
+    def read_state(self, path: str) -> float:
+        t = C.c_double()
+        self._ck(self._L.ekpnp_group_read_state(self._g, os.fsencode(path), C.byref(t)))
+        return t.value

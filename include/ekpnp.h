@@ -151,6 +151,14 @@ int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t);
 /* void fast_Poisson(charge, chargen, kx, ky, kz, plan) — LBM.h:176, poisson.cu:75-103,
  * including its efield() tail (poisson.cu:28-69): phi, Ex, Ey, Ez from c, cn. */
 int ekpnp_fast_poisson(ekpnp_ctx* ctx);
+/* The collide writes the Poisson right-hand side -F(c - cn)/eps from its registers, and
+ * ekpnp_fast_poisson uses it instead of re-reading c, cn when nothing has changed them since:
+ * ekpnp_set_field / ekpnp_read_* / ekpnp_bind_field invalidate it, and caller-bound c or cn
+ * arrays are ALWAYS re-read (like the reference's fast_Poisson reads charge_gpu at call time,
+ * poisson.cu:83).  A host that changes the library's OWN c / cn arrays on the device through
+ * ekpnp_field_device_ptr between the two calls says so with this call.  Either way the result is
+ * the same bits (one shared expression, poisson.cu:121-135). */
+int ekpnp_invalidate_rhs(ekpnp_ctx* ctx);
 
 /* The time loop body of main.cu:189-200, n times:
  * stream_collide_save; fast_Poisson; t += dt. */
@@ -246,6 +254,64 @@ int ekpnp_pbe_relax(ekpnp_ctx* ctx);
 int ekpnp_pbe_end(ekpnp_ctx* ctx);
 /* t += dt (main.cu:200) for hosts that drive the split calls themselves. */
 int ekpnp_advance_time(ekpnp_ctx* ctx);
+
+/* ---- the z-slab path's own transport (no reference counterpart) ------------
+ * The split entry points above leave the halo transport to the caller.  The library can also do
+ * it itself, over RCCL (ncclSend/ncclRecv ring + ncclAllGather over xGMI, librccl.so.1 bound on
+ * first use) or, between slabs of one process, by hipMemcpyPeerAsync.  Transfers run on a
+ * per-slab comm stream of the highest priority the device offers and are tied to the compute
+ * stream by events only, so the population halo exchange overlaps the collision of the slab's
+ * interior planes.  With a transport the reference's verbs work on slabs like on a whole lattice. */
+#define EKPNP_TRANSPORT_AUTO 0 /* RCCL when every slab has a device of its own, else COPY          */
+#define EKPNP_TRANSPORT_RCCL 1
+#define EKPNP_TRANSPORT_COPY 2 /* in-process groups only                                           */
+#define EKPNP_UNIQUE_ID_BYTES 128
+
+/* One process per GPU (bench.py under torch.distributed.run, an MPI host, ...): ONE rank makes an
+ * id (ncclGetUniqueId), the host hands it to every rank by its own means, and every rank attaches
+ * its slab context - collectively: this is ncclCommInitRank with the context's rank / nranks.
+ * From then on ekpnp_initialization, ekpnp_initialization_converged, ekpnp_stream_collide_save,
+ * ekpnp_fast_poisson, ekpnp_step, ekpnp_current / ekpnp_umax (combined over the ranks),
+ * ekpnp_record_umax, ekpnp_save_data_tecplot, ekpnp_save_data_end and ekpnp_read_data (ONE
+ * whole-lattice file, the ranks take turns in z order) work on the slab context; every rank must
+ * make the same calls in the same order.  ekpnp_destroy releases the communicator. */
+int ekpnp_comm_unique_id(void* id128);
+int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128);
+
+/* One process, several GPUs (ekpnp_main --gpus N): a group is nslabs slab contexts, slab i on HIP
+ * device devices[i] (devices == NULL: i modulo the device count), created, stepped and destroyed
+ * together by one host thread.  Devices may repeat (then the transport is COPY: RCCL refuses two
+ * ranks on one device) - that is how the whole multi-slab path is tested on a one-GPU box.  The
+ * calls mirror the single-context ones (same reference citations); fields cross the boundary as
+ * whole-lattice host arrays [NZ][NY][NX]; files are the single-context formats byte for byte. */
+typedef struct ekpnp_group ekpnp_group;
+int ekpnp_group_create(const ekpnp_params* p, int nslabs, const int* devices, int transport, ekpnp_group** out);
+int ekpnp_group_destroy(ekpnp_group* g);
+const char* ekpnp_group_last_error(const ekpnp_group* g); /* g == NULL: of the last failing ekpnp_group_create */
+int ekpnp_group_size(const ekpnp_group* g);
+int ekpnp_group_transport(const ekpnp_group* g);          /* EKPNP_TRANSPORT_RCCL or _COPY */
+int ekpnp_group_context(ekpnp_group* g, int slab, ekpnp_ctx** ctx); /* borrowed: for ekpnp_local_extent, timing hooks ... */
+size_t ekpnp_group_device_bytes(const ekpnp_group* g);
+int ekpnp_group_synchronize(ekpnp_group* g);
+int ekpnp_group_set_field(ekpnp_group* g, int field_id, const double* host);
+int ekpnp_group_get_field(ekpnp_group* g, int field_id, double* host);
+int ekpnp_group_initialization(ekpnp_group* g);                       /* LBM.cu:68-109  */
+int ekpnp_group_initialization_converged(ekpnp_group* g, double rel_tol, int max_sweeps, int* sweeps_done, double* residual);
+int ekpnp_group_init_equilibrium(ekpnp_group* g);                     /* LBM.cu:150-160 */
+int ekpnp_group_stream_collide_save(ekpnp_group* g, double t);        /* LBM.cu:465-481 */
+int ekpnp_group_fast_poisson(ekpnp_group* g);                         /* poisson.cu:75-103 */
+int ekpnp_group_step(ekpnp_group* g, int nsteps);                     /* main.cu:189-200 */
+int ekpnp_group_get_time(ekpnp_group* g, double* t);
+int ekpnp_group_set_time(ekpnp_group* g, double t);
+int ekpnp_group_current(ekpnp_group* g, double* I);                   /* LBM.cu:2674-2710 */
+int ekpnp_group_umax(ekpnp_group* g, double* umax);                   /* LBM.cu:2712-2753 */
+int ekpnp_group_record_umax(ekpnp_group* g, const char* path, int append, double time);
+int ekpnp_group_save_data_tecplot(ekpnp_group* g, const char* path, int append, double time, int first); /* LBM.cu:2492-2565 */
+int ekpnp_group_save_data_end(ekpnp_group* g, const char* path, int append, double time);                /* LBM.cu:2567-2630 */
+int ekpnp_group_read_data(ekpnp_group* g, const char* path, double* time);                               /* LBM.cu:2632-2671 */
+/* one EKPNPST1 file for the whole lattice: interchangeable with a single context's ekpnp_save_state */
+int ekpnp_group_save_state(ekpnp_group* g, const char* path, double time);
+int ekpnp_group_read_state(ekpnp_group* g, const char* path, double* time);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,12 @@ typedef struct oracle_state {
   double w[Q];
 } oracle_state;
 
+/* Lattices the sweeps work on.  The reference always runs four (LBM.cu:483-485).  n_lattices = 1 is
+ * BASELINE cfg1 (fluid lattice only: chargeinf = 0, Ra = 0, TH = 0): the three scalar lattices are
+ * identically zero there and the Poisson solve returns the constant wall potential, so skipping
+ * them changes no fluid result - only the time the CPU baseline leg of bench.py measures. */
+#define NLAT(s) ((s)->p.n_lattices == 1 ? 1 : 4)
+
 static inline size_t sidx(const oracle_state* s, int x, int y, int z) {
   return (size_t)s->p.nx * ((size_t)s->p.ny * z + y) + x; /* LBM.cu:22-25 */
 }
@@ -305,7 +311,7 @@ void oracle_init_equilibrium(oracle_state* s) {
         equilibrium(s, c, ux + p->K * Ex, uy + p->K * Ey, uz + p->K * Ez, eq[1]);
         equilibrium(s, cn, ux + p->Kn * Ex, uy + p->Kn * Ey, uz + p->Kn * Ez, eq[2]);
         equilibrium(s, T, ux, uy, uz, eq[3]);
-        for (int l = 0; l < 4; ++l) {
+        for (int l = 0; l < NLAT(s); ++l) {
           s->x0[l][i] = eq[l][0];
           for (int d = 1; d < Q; ++d) s->x1[l][nidx(s, x, y, z, d)] = eq[l][d];
         }
@@ -362,6 +368,7 @@ void oracle_collide_save(oracle_state* s) {
   const double F = p->convertCtoCharge;
   const int NX = p->nx, NY = p->ny, NZ = p->nz;
   const size_t plane = (size_t)NX * NY;
+  const int NL = NLAT(s);
 
   /* canonicalisation (1): keep plane z=1's pre-collision rest populations for the z==0 override */
   double* rest1[4];
@@ -379,8 +386,8 @@ void oracle_collide_save(oracle_state* s) {
         if (z == 0) s->f0bc[sidx(s, x, y, 0)] = s->x0[0][i];
         if (z == NZ - 1) s->f0bc[sidx(s, x, y, 1)] = s->x0[0][i];
 
-        double ft[4][Q];
-        for (int l = 0; l < 4; ++l) load_node(s, l, x, y, z, s->x0[l], ft[l]);
+        double ft[4][Q] = {{0.0}};
+        for (int l = 0; l < NL; ++l) load_node(s, l, x, y, z, s->x0[l], ft[l]);
         double rho = sum27(ft[0]);
         double rhoinv = 1.0 / rho;
         double charge = sum27(ft[1]), chargen = sum27(ft[2]), temp = sum27(ft[3]);
@@ -422,9 +429,11 @@ void oracle_collide_save(oracle_state* s) {
         /* equilibria, LBM.cu:830-1103 */
         double fe[4][Q];
         equilibrium(s, rho, ux, uy, uz, fe[0]);
-        equilibrium(s, charge, ux + p->K * Ex, uy + p->K * Ey, uz + p->K * Ez, fe[1]);
-        equilibrium(s, chargen, ux + p->Kn * Ex, uy + p->Kn * Ey, uz + p->Kn * Ez, fe[2]);
-        equilibrium(s, temp, ux, uy, uz, fe[3]);
+        if (NL > 1) {
+          equilibrium(s, charge, ux + p->K * Ex, uy + p->K * Ey, uz + p->K * Ez, fe[1]);
+          equilibrium(s, chargen, ux + p->Kn * Ex, uy + p->Kn * Ey, uz + p->Kn * Ez, fe[2]);
+          equilibrium(s, temp, ux, uy, uz, fe[3]);
+        }
 
         /* Guo force populations, LBM.cu:1107-1145 */
         double fpop[Q];
@@ -476,10 +485,12 @@ void oracle_collide_save(oracle_state* s) {
         /* TRT, LBM.cu:1700-1845 */
         double out[4][Q];
         trt(ft[0], fe[0], source, omega_plus * dt, omega_minus * dt, dt, out[0]);
-        trt(ft[1], fe[1], NULL, omega_c_plus * dt, omega_c_minus * dt, dt, out[1]);
-        trt(ft[2], fe[2], NULL, omega_cn_plus * dt, omega_cn_minus * dt, dt, out[2]);
-        trt(ft[3], fe[3], NULL, omega_T_plus * dt, omega_T_minus * dt, dt, out[3]);
-        for (int l = 0; l < 4; ++l) {
+        if (NL > 1) {
+          trt(ft[1], fe[1], NULL, omega_c_plus * dt, omega_c_minus * dt, dt, out[1]);
+          trt(ft[2], fe[2], NULL, omega_cn_plus * dt, omega_cn_minus * dt, dt, out[2]);
+          trt(ft[3], fe[3], NULL, omega_T_plus * dt, omega_T_minus * dt, dt, out[3]);
+        }
+        for (int l = 0; l < NL; ++l) {
           s->x0[l][i] = out[l][0];
           for (int d = 1; d < Q; ++d) s->x2[l][nidx(s, x, y, z, d)] = out[l][d];
         }
@@ -549,6 +560,7 @@ void oracle_boundary(oracle_state* s) {
 void oracle_stream(oracle_state* s) {
   const ekpnp_params* p = &s->p;
   const int NX = p->nx, NY = p->ny, NZ = p->nz;
+  const int NL = NLAT(s);
 #pragma omp parallel for
   for (int z = 0; z < NZ; ++z)
     for (int y = 0; y < NY; ++y)
@@ -556,7 +568,7 @@ void oracle_stream(oracle_state* s) {
         for (int d = 1; d < Q; ++d) {
           int xs = (x - EX[d] + NX) % NX, ys = (y - EY[d] + NY) % NY, zs = (z - EZ[d] + NZ) % NZ;
           size_t dst = nidx(s, x, y, z, d), src = nidx(s, xs, ys, zs, d);
-          for (int l = 0; l < 4; ++l) s->x1[l][dst] = s->x2[l][src];
+          for (int l = 0; l < NL; ++l) s->x1[l][dst] = s->x2[l][src];
         }
 }
 
@@ -564,6 +576,7 @@ void oracle_stream(oracle_state* s) {
 void oracle_bc_charge(oracle_state* s) {
   const ekpnp_params* p = &s->p;
   const int NZ = p->nz;
+  if (NLAT(s) == 1) return;
   for (int wall = 0; wall < 2; ++wall) {
     int z = wall ? NZ - 1 : 0;
     double TH = wall ? 0.0 : p->TH; /* LBM.cu:2226-2229 vs 2357-2412 */
@@ -826,6 +839,6 @@ double oracle_umax(oracle_state* s) {
 void oracle_step(oracle_state* s, int nsteps) {
   for (int i = 0; i < nsteps; ++i) {
     oracle_stream_collide_save(s);
-    oracle_fast_poisson(s);
+    if (NLAT(s) > 1) oracle_fast_poisson(s); /* cfg1 (fluid only): c = cn = 0, phi never enters */
   }
 }

@@ -32,3 +32,30 @@ def test_workload_follows_the_free_memory():
     assert b.parse_workload("auto", 100 * gb)[:3] == ("cfg2", (256, 256, 256), 3)
     assert b.parse_workload("cfg1", 0)[1:3] == ((64, 64, 64), 1)
     assert b.parse_workload("512x512x1024", 0, True) == ("512x512x1024", (512, 512, 1024), 4, True)
+
+
+def test_plain_invocation_with_gpus_spawns_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` invoked plainly (the way the driver invokes --gpus 1) must start
+    its two ranks itself - as child processes, before anything touches a GPU - relay rank 0's one
+    JSON line and return the child's exit code.  --dry-run stops after the rendezvous and a barrier,
+    so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["metric"].startswith("MLUPS")
+
+
+def test_world_size_must_match_gpus():
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RANK="0", WORLD_SIZE="3", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr

@@ -1,0 +1,241 @@
+"""GPU tests of the library's own z-slab transport (csrc/slab_team.hip) through the C ABI:
+ekpnp_group_* (one process, P slabs) and ekpnp_slab_attach_comm (one process per rank).
+
+The comparisons are against the ORACLE (the CPU restatement of the reference's step), not against
+the single-context HIP run: grids 16x12x16, 70x5x32, 130x4x64, P = 2, 4, 8, two-buffer and
+in-place populations.  A one-GPU box cannot hold two RCCL ranks on its device (RCCL refuses), so
+multi-slab groups there move their halos by device copies (EKPNP_TRANSPORT_COPY: same events,
+same comm streams, same call order) and RCCL is exercised with ONE rank whose ring closes on
+itself: every halo, all-gather and phi exchange then goes through ncclSend/ncclRecv/ncclAllGather
+inside the library."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL, TOL_U = 1e-9, 1e-7
+
+
+def _mirror(pkg, po):
+    p = pkg.Params()
+    for name, _ in p._fields_:
+        setattr(p, name, getattr(po, name))
+    return p
+
+
+def _oracle_run(O, po, steps):
+    orc = O.Oracle(po)
+    orc.initialization()
+    init = orc.fields()
+    start = O.perturb_fields(po, init)
+    orc.set_fields(start)
+    orc.fast_poisson()
+    pois = orc.fields()
+    orc.init_equilibrium()
+    orc.step(steps)
+    out = orc.fields()
+    cur, um = orc.current(), orc.umax()
+    orc.close()
+    return init, start, pois, out, cur, um
+
+
+def _check(O, got, want, groups=None, where=""):
+    err = O.rel_l2(got, want, groups or O.GROUPS)
+    bad = {k: v for k, v in err.items() if not v <= (TOL_U if k == "u" else TOL)}
+    assert not bad, (where, err)
+
+
+def _drive(O, run, po, ref, steps):
+    """the same call sequence on anything that speaks the reference's verbs"""
+    init, start, pois, out, cur, um = ref
+    run.initialization()
+    _check(O, run.fields(), init, {k: v for k, v in O.GROUPS.items() if k != "u"}, "init")
+    run.set_fields(start)
+    run.fast_Poisson()
+    _check(O, run.fields(), pois, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]}, "poisson")
+    run.init_equilibrium()
+    run.step(steps)
+    _check(O, run.fields(), out, where=f"step {steps}")
+    assert abs(run.current() - cur) <= 1e-8 * abs(cur)
+    assert abs(run.umax() - um) <= 1e-6 * abs(um) + 1e-30
+
+
+CASES = [((16, 12, 16), 2), ((16, 12, 16), 4), ((70, 5, 32), 2), ((70, 5, 32), 4), ((70, 5, 32), 8), ((130, 4, 64), 2), ((130, 4, 64), 4),
+         ((130, 4, 64), 8)]
+
+
+@pytest.mark.parametrize("in_place", [0, 1])
+@pytest.mark.parametrize("shape,nslabs", CASES)
+def test_group_of_slabs_vs_oracle(pkg, O, shape, nslabs, in_place):
+    po = O.default_params(*shape)
+    po.pb_iterations = 15
+    ref = _oracle_run(O, po, 7)
+    p = _mirror(pkg, po)
+    p.in_place = in_place
+    with pkg.Group(p, nslabs, devices=[0] * nslabs) as g:
+        assert g.transport == pkg.TRANSPORT_COPY and g.n == nslabs
+        assert [g.slab_extent(i) for i in range(nslabs)] == [(i * shape[2] // nslabs, shape[2] // nslabs) for i in range(nslabs)]
+        _drive(O, g, po, ref, 7)
+
+
+@pytest.mark.parametrize("in_place", [0, 1])
+def test_one_rank_rccl_group_vs_oracle(pkg, O, in_place):
+    """EKPNP_TRANSPORT_RCCL with one slab: ncclCommInitAll on one device, the ring closes on the rank."""
+    po = O.default_params(70, 5, 32)
+    po.pb_iterations = 15
+    ref = _oracle_run(O, po, 7)
+    p = _mirror(pkg, po)
+    p.in_place = in_place
+    with pkg.Group(p, 1, devices=[0], transport=pkg.TRANSPORT_RCCL) as g:
+        assert g.transport == pkg.TRANSPORT_RCCL
+        _drive(O, g, po, ref, 7)
+
+
+def test_attached_comm_makes_the_reference_verbs_work_on_a_slab(pkg, O):
+    """One process per rank as bench.py runs it: ekpnp_comm_unique_id on one rank, every rank
+    ekpnp_slab_attach_comm (ncclCommInitRank), then the plain verbs on the slab context.  One rank
+    here (a second rank would need a second GPU)."""
+    po = O.default_params(48, 6, 24)
+    po.pb_iterations = 12
+    ref = _oracle_run(O, po, 6)
+    p = _mirror(pkg, po)
+    s = pkg.Solver(p, 0, 1, slab=True)
+    try:
+        with pytest.raises(pkg.EkpnpError, match="transport"):
+            s.step(1)  # no transport yet: refuses instead of computing something else
+        s.attach_comm(pkg.comm_unique_id())
+        with pytest.raises(pkg.EkpnpError, match="already"):
+            s.attach_comm(pkg.comm_unique_id())
+        _drive(O, s, po, ref, 6)
+        n, res = s.initialization_converged(1e-9, 2000)
+        assert 0 < n < 2000 and res <= 1e-9
+    finally:
+        s.close()
+
+
+def test_group_rejects_what_it_cannot_do(pkg):
+    p = pkg.default_params(16, 8, 16)
+    with pytest.raises(pkg.EkpnpError, match="RCCL"):
+        pkg.Group(p, 2, devices=[0, 0], transport=pkg.TRANSPORT_RCCL)
+    with pytest.raises(pkg.EkpnpError):
+        pkg.Group(p, 5, devices=[0] * 5)  # 16 planes / 5 slabs
+    with pytest.raises(pkg.EkpnpError):
+        pkg.Group(p, 2, devices=[0, 99])
+    with pkg.Group(p, 2, devices=[0, 0]) as g:
+        import ctypes as C
+
+        h = g.slab_handle(0)
+        assert pkg.load_library().ekpnp_step(h, 1) != 0  # a member is driven through the group only
+        assert b"ekpnp_group" in pkg.load_library().ekpnp_last_error(h)
+
+
+def test_group_files_and_diagnostics_are_the_single_context_ones(pkg, O, tmp_path):
+    """data.dat / data_end.dat / umax.dat written by a 4-slab group are byte-identical to a single
+    context's (LBM.cu:2492-2630,2748), read_data and the EKPNPST1 state file are interchangeable
+    between the two, current() and umax agree."""
+    shape = (20, 6, 24)
+    p = pkg.default_params(*shape)
+    p.pb_iterations = 10
+    po = O.default_params(*shape)
+    with pkg.Solver(p) as s:
+        s.initialization()
+        s.set_fields(O.perturb_fields(po, s.fields()))
+        s.fast_Poisson(); s.init_equilibrium(); s.step(5)
+        f1 = s.fields()
+        s.save_data_tecplot(str(tmp_path / "a.dat"), 1.5e-9, first=True)
+        s.save_data_tecplot(str(tmp_path / "a.dat"), 2.5e-9, first=False, append=True)
+        s.save_data_end(str(tmp_path / "a_end.dat"), 2.5e-9)
+        s.record_umax(str(tmp_path / "a_umax.dat"), 2.5e-9, append=False)
+        s.save_state(str(tmp_path / "a.bin"), 2.5e-9)
+        cur1, um1 = s.current(), s.umax()
+    with pkg.Group(p, 4, devices=[0] * 4) as g:
+        g.set_fields(f1)
+        g.save_data_tecplot(str(tmp_path / "b.dat"), 1.5e-9, first=True)
+        g.save_data_tecplot(str(tmp_path / "b.dat"), 2.5e-9, first=False, append=True)
+        g.save_data_end(str(tmp_path / "b_end.dat"), 2.5e-9)
+        g.record_umax(str(tmp_path / "b_umax.dat"), 2.5e-9, append=False)
+        g.save_state(str(tmp_path / "b.bin"), 2.5e-9)
+        assert g.current() == cur1 and g.umax() == um1
+        for a, b in (("a.dat", "b.dat"), ("a_end.dat", "b_end.dat"), ("a_umax.dat", "b_umax.dat"), ("a.bin", "b.bin")):
+            assert (tmp_path / a).read_bytes() == (tmp_path / b).read_bytes(), (a, b)
+        # restart from the text file (lossy %10.6f, like the reference) and from the state file
+        g.set_fields({k: np.zeros(g.shape) for k in pkg.FIELDS})
+        assert g.read_state(str(tmp_path / "a.bin")) == 2.5e-9
+        got = g.fields()
+        for k in f1:
+            assert np.array_equal(got[k], f1[k]), k
+        t = g.read_data(str(tmp_path / "a_end.dat"))
+        assert abs(t - 2.5e-9) < 1e-6
+        txt = g.fields()
+    with pkg.Solver(p) as s:
+        s.read_data(str(tmp_path / "b_end.dat"))
+        one = s.fields()
+        assert s.read_state(str(tmp_path / "b.bin")) == 2.5e-9
+        back = s.fields()
+    for k in f1:
+        assert np.array_equal(txt[k], one[k]), k
+        assert np.array_equal(back[k], f1[k]), k
+
+
+def test_group_converged_start_equals_single_context(pkg, O):
+    shape = (16, 8, 160)  # taller than the ~180 planes? no: 160 planes still converge with the reduced damping
+    p = pkg.default_params(*shape)
+    with pkg.Solver(p) as s:
+        n1, r1 = s.initialization_converged(1e-8, 4000)
+        f1 = s.fields()
+    with pkg.Group(p, 4, devices=[0] * 4) as g:
+        n4, r4 = g.initialization_converged(1e-8, 4000)
+        f4 = g.fields()
+    assert n1 == n4 and 0 < n1 < 4000
+    err = O.rel_l2(f4, f1, {k: v for k, v in O.GROUPS.items() if k != "u"})
+    assert max(err.values()) < 1e-10, err
+
+
+def test_cpp_driver_with_slabs_writes_the_single_gpu_files(pkg, tmp_path):
+    """ekpnp_main --gpus N (csrc/ekpnp_main.cpp over ekpnp_group_*): main.cu's whole sequence -
+    initialization, time loop with Tecplot zones / current / umax lines, data_end.dat - on 4 z
+    slabs gives the files of the one-GPU run.  The slabs solve the z-tridiagonal system in a
+    different association (interface system), so the comparison is numeric, at the precision of
+    the text formats (%g: 6 significant digits, %10.6f)."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ek-pnp-3d_amd", "ekpnp_main")
+    if not os.path.exists(exe):
+        pytest.skip("ekpnp_main not built")
+    geo = ["--nx", "24", "--ny", "6", "--nz", "32", "--steps", "40", "--nsave", "15", "--print-current", "10"]
+    outs = {}
+    for tag, extra in (("one", []), ("four", ["--devices", "0,0,0,0"]), ("rccl1", ["--devices", "0", "--transport", "rccl"])):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([exe, *geo, "--out", str(d), "--binary-state", "1", *extra], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        if tag == "four":
+            assert "z slabs: 4, halo transport: device copies" in r.stdout
+        if tag == "rccl1":
+            assert "z slabs: 1, halo transport: RCCL" in r.stdout
+        outs[tag] = (d, [float(l.split("Current = ")[1]) for l in r.stdout.splitlines() if "Current = " in l])
+    one, cur1 = outs["one"]
+    assert len(cur1) == 4
+    for tag in ("four", "rccl1"):
+        d, cur = outs[tag]
+        assert np.allclose(cur, cur1, rtol=2e-5), (tag, cur, cur1)
+        a, b = np.loadtxt(one / "data_end.dat"), np.loadtxt(d / "data_end.dat")
+        assert a.shape == b.shape == (24 * 6 * 32, 12) and np.abs(a - b).max() <= 2e-6
+        ua, ub = np.loadtxt(one / "umax.dat"), np.loadtxt(d / "umax.dat")
+        assert ua.shape == ub.shape and np.abs(ua - ub).max() <= 2e-6
+        la, lb = (one / "data.dat").read_text().splitlines(), (d / "data.dat").read_text().splitlines()
+        assert len(la) == len(lb) and [l for l in la if not l[:1].isdigit()] == [l for l in lb if not l[:1].isdigit()]  # headers, ZONE lines
+        sa, sb = np.fromfile(one / "data_end.bin", dtype=np.float64, offset=40), np.fromfile(d / "data_end.bin", dtype=np.float64, offset=40)
+        n = 24 * 6 * 32
+        for i, k in enumerate(pkg.FIELDS):  # the lossless file: rounding-level agreement field by field
+            x, y = sa[i * n:(i + 1) * n], sb[i * n:(i + 1) * n]
+            assert np.abs(x - y).max() <= 1e-9 * (np.abs(x).max() + 1e-300) + (1e-11 if k.startswith("u") else 0.0), (tag, k)
+    # restart of the slab run from its own whole-lattice files
+    d = outs["four"][0]
+    r = subprocess.run([exe, "--nx", "24", "--ny", "6", "--nz", "32", "--steps", "2", "--devices", "0,0,0,0", "--read-previous", "2", "--out", str(d)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Reading previous data (binary)" in r.stdout, r.stderr[-2000:]
+    r = subprocess.run([exe, "--nx", "24", "--ny", "6", "--nz", "32", "--steps", "2", "--devices", "0,0,0,0", "--read-previous", "1", "--out", str(d)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Reading previous data..." in r.stdout, r.stderr[-2000:]

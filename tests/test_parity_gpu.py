@@ -491,3 +491,84 @@ def test_in_place_mode_vs_oracle(pkg, O):
     p.in_place = 2
     with pytest.raises(pkg.EkpnpError):
         pkg.Solver(p)
+
+
+def test_fast_poisson_same_bits_from_fused_and_from_reread_rhs(pkg, O):
+    """The collide writes the Poisson right-hand side from its registers; ekpnp_fast_poisson may use
+    it or rebuild it from c, cn (after set_field, invalidate_rhs, or whenever c / cn are
+    caller-bound).  Both producers share ONE expression (poisson.cu:121-135 order), so phi and E
+    must be the same bits whichever path ran."""
+    import torch
+
+    po = O.default_params(70, 6, 19)
+    po.pb_iterations = 8
+    p = _mirror(pkg, po)
+    res = []
+    for mode in ("fused", "set_field", "invalidate", "bound"):
+        with pkg.Solver(p) as s:
+            keep = None
+            if mode == "bound":
+                keep = [torch.zeros(s.shape, dtype=torch.float64, device="cuda") for _ in range(2)]
+                s.bind_field("c", keep[0].data_ptr())
+                s.bind_field("cn", keep[1].data_ptr())
+            s.initialization()
+            s.set_fields(O.perturb_fields(po, s.fields()))
+            s.fast_Poisson(); s.init_equilibrium()
+            for _ in range(3):
+                s.stream_collide_save()
+                if mode == "set_field":
+                    s.set_field("c", s.get_field("c"))
+                elif mode == "invalidate":
+                    s.invalidate_rhs()
+                s.fast_Poisson()
+            res.append(s.fields())
+    for other in res[1:]:
+        for k in res[0]:
+            assert np.array_equal(res[0][k], other[k]), k
+
+
+def test_bound_concentrations_are_read_at_call_time(pkg, O):
+    """The reference's fast_Poisson reads charge_gpu / chargen_gpu when it is called
+    (poisson.cu:83).  A host that changes its own (bound) c array on the device between
+    stream_collide_save and fast_Poisson must get the potential of the CHANGED charge."""
+    import torch
+
+    po = O.default_params(24, 6, 17)
+    po.pb_iterations = 5
+    p = _mirror(pkg, po)
+    with pkg.Solver(p) as s:
+        c = torch.zeros(s.shape, dtype=torch.float64, device="cuda")
+        cn = torch.zeros(s.shape, dtype=torch.float64, device="cuda")
+        s.bind_field("c", c.data_ptr()); s.bind_field("cn", cn.data_ptr())
+        s.initialization(); s.init_equilibrium()
+        s.stream_collide_save(); s.synchronize()
+        c.mul_(1.25)  # a custom source kernel of the host, on the device
+        torch.cuda.synchronize()
+        s.fast_Poisson()
+        got = s.get_field("phi")
+        want_c, want_cn = c.cpu().numpy(), cn.cpu().numpy()
+    orc = O.Oracle(po)
+    orc.gpu_initialization()
+    orc.set_fields({"c": want_c, "cn": want_cn})
+    orc.fast_poisson()
+    assert np.abs(got - orc.field("phi")).max() <= 1e-12 * np.abs(got).max()
+
+
+def test_bench_start_profile_from_the_product_vs_gouy_chapman(pkg):
+    """bench.py builds its tall-channel start with the product (ekpnp_initialization_converged on a
+    narrow replica); the closed-form Gouy-Chapman double layer is only the known answer here: the
+    discrete PB solution agrees with it to the discretisation error of a 9.2-node Debye length."""
+    import bench
+
+    p = pkg.default_params(64, 64, 512)
+    prof, note = bench.pb_profile_from_product(pkg, p)
+    assert "replica" in note and prof["phi"].shape == (512,)
+    z = np.arange(512, dtype=np.float64)
+    lam = np.sqrt(p.eps * p.kB * p.roomT / p.electron / (2 * p.chargeinf * p.convertCtoCharge))
+    vt = p.kB * p.roomT / p.electron
+    wall = lambda zeta, d: 4 * vt * np.arctanh(np.tanh(zeta / (4 * vt)) * np.exp(-d / lam))  # noqa: E731
+    gc = wall(p.voltage, z * p.dz) + wall(p.voltage2, (511 - z) * p.dz)
+    assert np.abs(prof["phi"] - gc).max() < 0.01 * abs(p.voltage)
+    assert prof["phi"][0] == p.voltage and prof["phi"][-1] == p.voltage2
+    assert np.allclose(prof["c"] * prof["cn"], p.chargeinf**2, rtol=1e-9)  # Boltzmann
+    assert abs(prof["phi"][256]) < 1e-9  # the double layers do not reach the mid-plane

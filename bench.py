@@ -25,10 +25,13 @@ import os
 import sys
 import time
 
-# thread placement of the CPU-baseline leg; an OpenMP runtime reads these once, when
-# it starts, so they are set before anything that brings one in is imported
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
+# CPUs this process may run on, read BEFORE anything brings an OpenMP runtime in: with OMP_PROC_BIND
+# set (the CPU-baseline child below) the runtime binds the initial thread to its first place when it
+# starts, and the affinity mask read afterwards is that one core
+try:
+    _CPUS_AT_START = len(os.sched_getaffinity(0))
+except AttributeError:
+    _CPUS_AT_START = os.cpu_count() or 1
 
 import numpy as np  # noqa: E402
 
@@ -162,7 +165,9 @@ def cpu_baseline(nl: int, budget_s: float = 20.0):
         on ONE core.
     Bounded to about budget_s seconds in total."""
     O = G.load_oracle()
-    cores = O.host_cores()
+    # like oracle.host_cores(): OMP_NUM_THREADS if set, else min(16, CPUs of the affinity mask) - the GPU
+    # box grants about 16 cores per GPU while exposing every hardware thread of the host
+    cores = max(1, int(os.environ["OMP_NUM_THREADS"])) if os.environ.get("OMP_NUM_THREADS") else max(1, min(16, _CPUS_AT_START))
     legs = []
     shape = (128, 128, 65)
     p = O.default_params(*shape)
@@ -186,9 +191,25 @@ def cpu_baseline(nl: int, budget_s: float = 20.0):
         "sample": f"{main_leg['workload']}, {k} steps, OpenMP oracle ({dt:.1f} s)",
         "cpu_model": cpu_model(),
         "threads_available": cores,
+        "cpus_in_affinity_mask": _CPUS_AT_START,
         "pinning": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
         "legs": legs,
     }
+
+
+def cpu_baseline_in_child(nl: int):
+    """Runs cpu_baseline() in a child process whose environment pins the OpenMP threads
+    (OMP_PROC_BIND=close, OMP_PLACES=cores: BASELINE.md §3).  A child, because an OpenMP runtime
+    reads these once when it starts and then binds the INITIAL thread too - in the bench process
+    that would pin the thread that drives the GPU (and, under torch.distributed.run, the initial
+    threads of all ranks to the same core).  The child never touches a GPU."""
+    import subprocess
+
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(nl)], env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("CPU-baseline child failed: " + r.stderr[-2000:])
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
 def spawn_ranks(n: int, argv: list) -> int:
@@ -281,7 +302,11 @@ def main():
     ap.add_argument("--force-slab", action="store_true",
                     help="N=1 only: run the multi-rank code path (split calls, comm stream, RCCL exchanges, the ring closing on the same rank)")
     ap.add_argument("--dry-run", action="store_true", help="check the launch plumbing only: rendezvous, barrier, one JSON line; no GPU")
+    ap.add_argument("--cpu-baseline-only", type=int, default=None, metavar="LATTICES", help="internal: time the CPU oracle and print its JSON (the child of cpu_baseline_in_child)")
     args = ap.parse_args()
+    if args.cpu_baseline_only is not None:
+        print(json.dumps(cpu_baseline(args.cpu_baseline_only)), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -451,7 +476,7 @@ def main():
             try:
                 rec = json.load(open(tpath)).get(wname, {})
                 traffic = rec.get("hbm_bytes_per_launch")
-                traffic_src = {"file": "profiles/pmc_traffic.json", "profiled_in": rec.get("round"),
+                traffic_src = None if traffic is None else {"file": "profiles/pmc_traffic.json", "profiled_in": rec.get("round"),
                                "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of that committed profile, NOT measured by this run"}
             except Exception:
                 traffic = None
@@ -502,7 +527,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             runner.close()
-            out["cpu_baseline"] = cpu_baseline(nl)
+            out["cpu_baseline"] = cpu_baseline_in_child(nl)
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)

@@ -851,7 +851,21 @@ extern "C" int ekpnp_collide_interior_planes(ekpnp_ctx* ctx) {
   hipEvent_t* stop = nullptr;
   int rc = timing_begin(c, &stop);
   if (rc) return rc;
-  ordered_bulk(c, 1, c.nzl - 1);
+  // The halo transfer that was started before this call (comm stream) and the sweep below become
+  // ready at the same moment, and a single launch of ~10^6 workgroups keeps every wave slot of the
+  // chip refilled with its own workgroups until it drains: the workgroups of an RCCL kernel, which
+  // need more registers than one retiring collide wave frees, were only placed when the sweep
+  // ended (rocprofv3: the exchange kernel ended 0.1 ms AFTER a 39 ms sweep,
+  // profiles/r02_slab_overlap_before.json).  A short lead-in launch drains after ~0.1 ms and lets
+  // them in; the rest of the sweep then runs beside the transfer.
+  static const int lead_env = std::getenv("EKPNP_SLAB_LEAD_PLANES") ? std::atoi(std::getenv("EKPNP_SLAB_LEAD_PLANES")) : 2;
+  const int lead = (!c.inplace && lead_env > 0 && c.nzl - 2 > 4 * lead_env) ? lead_env : 0;
+  if (lead) {
+    launch_collide_bulk(c, 1, 1 + lead);
+    launch_collide_bulk(c, 1 + lead, c.nzl - 1);
+  } else {
+    ordered_bulk(c, 1, c.nzl - 1);
+  }
   if (stop) {
     HIPCHK(c, hipEventRecord(*stop, c.stream));
     c.timed_nodes = (long long)(c.nzl - 2) * (long long)c.plane;

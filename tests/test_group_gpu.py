@@ -239,3 +239,74 @@ def test_cpp_driver_with_slabs_writes_the_single_gpu_files(pkg, tmp_path):
     r = subprocess.run([exe, "--nx", "24", "--ny", "6", "--nz", "32", "--steps", "2", "--devices", "0,0,0,0", "--read-previous", "1", "--out", str(d)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "Reading previous data..." in r.stdout, r.stderr[-2000:]
+
+
+# ---- BASELINE cfg4 / cfg5 at their full per-rank shapes (size-independent properties) -------------
+
+def _uniform_profiles(run, p, steps):
+    """x-y uniform PB start from the product, `steps` steps; z profiles at (0,0) and the far corner"""
+    import bench
+
+    prof, _ = bench.pb_profile_from_product(_uniform_profiles.pkg, p)
+    bench.product_pb_state(run, p, prof)
+    run.fast_Poisson()
+    run.init_equilibrium()
+    run.step(steps)
+    out = {}
+    for k in ("rho", "c", "cn", "phi", "T", "Ez", "uz", "ux"):
+        v = run.get_field(k)
+        assert np.isfinite(v).all(), k
+        assert np.abs(v[:, -1, -1] - v[:, 0, 0]).max() <= 1e-12 * np.abs(v).max(), k  # uniform at the far corner of the index space too
+        out[k] = v[:, 0, 0].copy()
+    return out
+
+
+def _same_profiles(a, b):
+    for k in a:
+        tol = 1e-7 if k in ("uz", "ux") else 1e-11
+        assert np.abs(a[k] - b[k]).max() <= tol * np.abs(b[k]).max(), (k, np.abs(a[k] - b[k]).max(), np.abs(b[k]).max())
+
+
+def test_cfg4_whole_lattice_512x512x1024_in_place(pkg):
+    """cfg4's lattice (268 M nodes x 4 lattices, 276 GB in place - beyond the reference's 32-bit
+    indices) on one MI355X: an x-y uniform problem does not know NX, NY, so its z profiles must equal
+    those of a 64x64x1024 run (only the FFT sizes, i.e. rounding, differ)."""
+    import torch
+
+    _uniform_profiles.pkg = pkg
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 282e9:
+        pytest.skip("needs 277 GB of free HBM")
+    prof = {}
+    for n in (64, 512):
+        p = pkg.default_params(n, n, 1024)
+        p.in_place = 1
+        with pkg.Solver(p) as s:
+            prof[n] = _uniform_profiles(s, p, 3)
+            if n == 512:
+                assert s.device_bytes() > 270e9
+    _same_profiles(prof[512], prof[64])
+
+
+def test_cfg5_per_rank_slab_1024x1024x128_through_the_transport(pkg):
+    """cfg5's per-rank shape (1024x1024 planes, 128 of them: 302 MB of halo per direction and
+    step) on the multi-rank code path: a slab context with the library's RCCL transport attached,
+    one rank, the ring closing on itself.  Same property: equal to a 64x64x128 single-context run."""
+    import torch
+
+    _uniform_profiles.pkg = pkg
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 255e9:
+        pytest.skip("needs 250 GB of free HBM")
+    p = pkg.default_params(64, 64, 128)
+    with pkg.Solver(p) as s:
+        small = _uniform_profiles(s, p, 3)
+    p = pkg.default_params(1024, 1024, 128)
+    s = pkg.Solver(p, 0, 1, slab=True)
+    try:
+        s.attach_comm(pkg.comm_unique_id())
+        big = _uniform_profiles(s, p, 3)
+        assert s.device_bytes() > 245e9
+    finally:
+        s.close()
+    _same_profiles(big, small)

@@ -571,4 +571,4 @@ def test_bench_start_profile_from_the_product_vs_gouy_chapman(pkg):
     assert np.abs(prof["phi"] - gc).max() < 0.01 * abs(p.voltage)
     assert prof["phi"][0] == p.voltage and prof["phi"][-1] == p.voltage2
     assert np.allclose(prof["c"] * prof["cn"], p.chargeinf**2, rtol=1e-9)  # Boltzmann
-    assert abs(prof["phi"][256]) < 1e-9  # the double layers do not reach the mid-plane
+    assert abs(prof["phi"][256]) < 1e-7  # the double layers do not reach the mid-plane (2 zeta exp(-128/9.2) ~ 1e-8)

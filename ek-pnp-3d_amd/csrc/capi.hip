@@ -136,6 +136,7 @@ PArgs Ctx::pargs() const {
   a.rhs_wall_lo = p.voltage / p.dz / p.dz;
   a.rhs_wall_hi = p.voltage2 / p.dz / p.dz;
   a.dx = p.dx; a.dy = p.dy; a.dz = p.dz;
+  a.Lx = p.Lx; a.Ly = p.Ly;
   a.inv_nxny = 1.0 / ((double)p.nx * (double)p.ny);
   return a;
 }
@@ -230,7 +231,8 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   if ((rc = dev_alloc(c, (void**)&c.spec, (size_t)c.nzl * p->ny * c.nxh * sizeof(double2)))) return bail(rc);
   if (hipMemsetAsync(c.spec, 0, (size_t)c.nzl * p->ny * c.nxh * sizeof(double2), c.stream) != hipSuccess) { c.err = "hipMemsetAsync failed"; return bail(EKPNP_ERR_HIP); }
   const size_t nmodes = (size_t)p->ny * c.nxh;
-  const size_t cprime_rows = !slab ? (size_t)p->nz : (size_t)c.nzl + 2;
+  // slabs: the full table of their local rows; one context: only the rows its z solve restarts from
+  const size_t cprime_rows = !slab ? (size_t)(p->nz - 2) / TRI_CHECK + 1 : (size_t)c.nzl + 2;
   if ((rc = dev_alloc(c, (void**)&c.cprime, cprime_rows * nmodes * sizeof(double)))) return bail(rc);
   {
     const double vw[2] = {p->voltage, p->voltage2};

@@ -51,6 +51,7 @@ __host__ __device__ constexpr int dn_dir(int k) {
 // lie gigabytes apart (pure-copy ceiling of the two shapes on one box: 5.95 vs 5.48 TB/s,
 // profiles/r01_stream_probe_aosoa.log).  Lanes of the last tile beyond nx are never touched.
 constexpr int TILE = Q * 64;
+constexpr int TRI_CHECK = 16;  // the single-context z solve keeps every 16th row of c' and of d' (poisson.hip TRI_BS)
 __host__ __device__ inline long long pop_xoff(int x) { return (long long)(x >> 6) * TILE + (x & 63); }
 
 // Everything a kernel needs, passed by value.
@@ -94,13 +95,13 @@ struct PArgs {
   double* fld[EKPNP_NFIELDS];
   double* work;                // real [nzl][ny][nx]
   double2* spec;               // complex [nzl][ny][nxh]
-  const double* cprime;        // Thomas table [nz][ny][nxh] (global z index)
+  const double* cprime;        // Thomas factors c': slabs [nzl+2][ny][nxh] (local rows); single context every 16th row only
   const double* phi_lo;        // phi plane below / above the slab (slab mode), may be null
   const double* phi_hi;
   const double* vwall;         // {voltage, voltage2} in device memory
   int nx, ny, nz, nxh, nzl, z0;
   long long plane;
-  double F, eps, voltage, voltage2, dx, dy, dz, inv_nxny;
+  double F, eps, voltage, voltage2, dx, dy, dz, inv_nxny, Lx, Ly;
   double rhs_wall_lo, rhs_wall_hi;  // as in KArgs
 };
 

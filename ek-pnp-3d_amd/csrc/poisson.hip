@@ -29,25 +29,33 @@ __global__ void k_poisson_rhs(PArgs a) {
   a.work[i] = v;
 }
 
-// Thomas factorisation table of  phi[z-1] - (2 + kappa) phi[z] + phi[z+1] = dz^2 g[z],
-// kappa = dz^2 (kx^2 + ky^2), for interior planes z = 1 .. nz-2 of the GLOBAL lattice:
-// c'[1] = 1/b, c'[z] = 1/(b - c'[z-1]), b = -(2 + kappa).  Layout [nz][ny][nxh].
-__global__ void k_build_cprime(double* cprime, int nx, int ny, int nz, int nxh, double Lx, double Ly, double dz) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= ny * nxh) return;
+// Diagonal of the z system of one (kx,ky) mode:  phi[z-1] + b phi[z] + phi[z+1] = dz^2 g[z],
+// b = -(2 + dz^2 (kx^2 + ky^2)), wavenumbers exactly as main.cu:119-136.  (Pad columns of the half
+// spectrum get some b <= -2 too: their right-hand side is 0 and stays 0.)
+__device__ __forceinline__ double mode_diag(int m, int ny, int nxh, double Lx, double Ly, double dz) {
   const int ix = m % nxh, iy = m / nxh;
-  // wavenumbers exactly as main.cu:119-136
   const double kx = (double)ix * 2.0 * M_PI / Lx;
   const double ky = (iy <= ny / 2) ? (double)iy * 2.0 * M_PI / Ly : ((double)iy - ny) * 2.0 * M_PI / Ly;
-  const double b = -(2.0 + dz * dz * (kx * kx + ky * ky));
+  return -(2.0 + dz * dz * (kx * kx + ky * ky));
+}
+
+// Thomas factorisation of that system for the rows z = 1 .. nz-2:  c'[0] = 0, c'[z] = 1/(b - c'[z-1]).
+// Stored: every `every`-th row, table row k = c'[k * every], layout [rows][ny][nxh].  every = 1 is the
+// full table of the slab kernels; the single-context solve keeps only the rows it restarts the
+// recurrence from (every = TRI_BS) and recomputes the others - same operations, same bits, and the
+// table is neither read in the forward sweep nor read twice (0.55 GB per read on 512^3).
+__global__ void k_build_cprime(double* cprime, int nx, int ny, int nz, int nxh, double Lx, double Ly, double dz, int every) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= ny * nxh) return;
+  const double b = mode_diag(m, ny, nxh, Lx, Ly, dz);
   const long long ms = (long long)ny * nxh;
   double cp = 0.0;
   cprime[m] = 0.0;
   for (int z = 1; z <= nz - 2; ++z) {
     cp = 1.0 / (b - cp);
-    cprime[(long long)z * ms + m] = cp;
+    if (z % every == 0) cprime[(long long)(z / every) * ms + m] = cp;
   }
-  cprime[(long long)(nz - 1) * ms + m] = 0.0;
+  if (every == 1) cprime[(long long)(nz - 1) * ms + m] = 0.0;
 }
 
 // Forward elimination + back substitution for one (kx,ky) mode, in place on the spectrum.
@@ -57,22 +65,26 @@ __global__ void k_build_cprime(double* cprime, int nx, int ny, int nz, int nxh, 
 // of storing all of it (a second write + read of the whole spectrum) the forward sweep keeps only
 // every TRI_BS-th row (written over the spectrum row it belongs to) and the back substitution
 // recomputes the rows in between, block by block, from the untouched right-hand side: the same
-// operations in the same order, hence the same bits, for 4.4 instead of 5.5 GB on 512^3.
-constexpr int TRI_BS = 16;
+// operations in the same order, hence the same bits, for 4.4 instead of 5.5 GB on 512^3.  The
+// factors c' are treated the same way: the forward sweep runs their recurrence in registers (one
+// division per row, hidden behind the loads), the back substitution restarts it from the table row
+// below each block: 3.4 GB, i.e. the spectrum read twice and written once and nothing else.
+constexpr int TRI_BS = TRI_CHECK;
 __global__ void __launch_bounds__(64) k_tridiag(PArgs a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   const long long ms = (long long)a.ny * a.nxh;
   if (m >= ms) return;
   const double dz2 = a.dz * a.dz;
+  const double b = mode_diag(m, a.ny, a.nxh, a.Lx, a.Ly, a.dz);
   double2* s = a.spec + m;
-  const double* cp = a.cprime + m;
+  const double* ck = a.cprime + m;  // row k = c'[k * TRI_BS]
   const int n = a.nz;
   {
-    double dr = 0.0, di = 0.0;
+    double dr = 0.0, di = 0.0, c = 0.0;
 #pragma unroll 8
     for (int z = 1; z <= n - 2; ++z) {
       const double2 r = s[(long long)z * ms];
-      const double c = cp[(long long)z * ms];
+      c = 1.0 / (b - c);
       dr = (dz2 * r.x - dr) * c;
       di = (dz2 * r.y - di) * c;
       if ((z & (TRI_BS - 1)) == 0) s[(long long)z * ms] = make_double2(dr, di);  // checkpoint d'[z]
@@ -85,19 +97,22 @@ __global__ void __launch_bounds__(64) k_tridiag(PArgs a) {
     double2 d[TRI_BS];
     double c[TRI_BS];
     double2 prev = make_double2(0.0, 0.0);
-    if (zlo > 1) prev = s[(long long)(zlo - 1) * ms];
+    double cprev = 0.0;
+    if (zlo > 1) {
+      prev = s[(long long)(zlo - 1) * ms];
+      cprev = ck[(long long)((zlo - 1) / TRI_BS) * ms];
+    }
 #pragma unroll
     for (int i = 0; i < TRI_BS; ++i) {
       const int z = zlo + i;
-      if (z <= zhi) {
-        d[i] = s[(long long)z * ms];
-        c[i] = cp[(long long)z * ms];
-      }
+      if (z <= zhi) d[i] = s[(long long)z * ms];
     }
 #pragma unroll
     for (int i = 0; i < TRI_BS; ++i) {
       const int z = zlo + i;
       if (z <= zhi) {
+        cprev = 1.0 / (b - cprev);
+        c[i] = cprev;
         if (i != TRI_BS - 1) {  // not a checkpoint row: d[i] still holds the right-hand side
           d[i].x = (dz2 * d[i].x - prev.x) * c[i];
           d[i].y = (dz2 * d[i].y - prev.y) * c[i];
@@ -135,8 +150,7 @@ __global__ void __launch_bounds__(256) k_tridiag_pcr64(PArgs a) {
   if (md >= ms) return;  // wave-uniform
   const int m = a.nz - 2;  // unknown rows, <= 64
   const bool live = lane < m;
-  // b of this mode: cprime row 1 holds c'_1 = 1/b
-  const double bdiag = 1.0 / a.cprime[ms + md];
+  const double bdiag = mode_diag(md, a.ny, a.nxh, a.Lx, a.Ly, a.dz);
   double2* s = a.spec + md + (long long)(lane + 1) * ms;
   const double dz2 = a.dz * a.dz;
   double lo = live && lane > 0 ? 1.0 : 0.0;      // coefficient of x[i - stride]
@@ -484,7 +498,7 @@ int build_cprime(Ctx& c) {
   // single context: rows 1..nz-2 of the global system; slab: rows 1..nzl of a local block
   const int rows_nz = !c.slab ? c.p.nz : c.nzl + 2;
   hipLaunchKernelGGL(k_build_cprime, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.p.nx, c.p.ny, rows_nz, c.nxh, c.p.Lx,
-                     c.p.Ly, c.p.dz);
+                     c.p.Ly, c.p.dz, c.slab ? 1 : TRI_BS);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hipfail("k_build_cprime launch", e);
   if (c.slab) {

@@ -235,7 +235,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   const size_t cprime_rows = !slab ? (size_t)(p->nz - 2) / TRI_CHECK + 1 : (size_t)c.nzl + 2;
   if ((rc = dev_alloc(c, (void**)&c.cprime, cprime_rows * nmodes * sizeof(double)))) return bail(rc);
   {
-    const double vw[2] = {p->voltage, p->voltage2};
+    const double vw[4] = {p->voltage, p->voltage, p->voltage2, p->voltage2};  // pairs: the two-nodes-per-lane phi/E kernel loads 16 bytes
     if ((rc = dev_alloc(c, (void**)&c.vwall, sizeof(vw)))) return bail(rc);
     if (hipMemcpy(c.vwall, vw, sizeof(vw), hipMemcpyHostToDevice) != hipSuccess) { c.err = "hipMemcpy failed"; return bail(EKPNP_ERR_HIP); }
   }

@@ -98,7 +98,7 @@ struct PArgs {
   const double* cprime;        // Thomas factors c': slabs [nzl+2][ny][nxh] (local rows); single context every 16th row only
   const double* phi_lo;        // phi plane below / above the slab (slab mode), may be null
   const double* phi_hi;
-  const double* vwall;         // {voltage, voltage2} in device memory
+  const double* vwall;         // {voltage, voltage, voltage2, voltage2} in device memory
   int nx, ny, nz, nxh, nzl, z0;
   long long plane;
   double F, eps, voltage, voltage2, dx, dy, dz, inv_nxny, Lx, Ly;
@@ -189,7 +189,7 @@ struct Ctx {
   double* edge_all = nullptr;      // [nranks][4][modes]
   double* phi_old = nullptr;       // PB relaxation state (ekpnp_pbe_begin/end)
   double* diag = nullptr;          // reduction scratch (DIAG_SCRATCH doubles)
-  double* vwall = nullptr;         // {voltage, voltage2}
+  double* vwall = nullptr;         // {voltage, voltage, voltage2, voltage2}
   int collide_phase = 0;           // 0 idle, 1 boundary planes done
   // hipGraph of two consecutive steps (A->B, B->A) for launch-bound lattices
   hipGraphExec_t graph2 = nullptr;

@@ -13,6 +13,8 @@
 // (kx,ky)=(0,0) is a regular Dirichlet problem here, so the reference's DC-mode leak
 // (poisson.cu:177, mu := 1) cannot occur: this is the canonical "DC = 0" result.
 // It moves 4x fewer bytes than the 2N-point complex transform and has no constraint on NZ.
+#include <cstdlib>
+
 #include "ekpnp_internal.h"
 
 namespace ekpnp {
@@ -215,7 +217,7 @@ struct PhiColumn {
   const double* __restrict__ work;
   const double* __restrict__ lo;
   const double* __restrict__ hi;
-  const double* __restrict__ vwall;  // {voltage, voltage2} in device memory: the wall case is a pointer select too
+  const double* __restrict__ vwall;  // {voltage, voltage, voltage2, voltage2} in device memory: the wall case is a pointer select too
   long long plane, oc;
   int z0, nzl, nz;
   double inv;
@@ -229,10 +231,33 @@ struct PhiColumn {
     p = zl < 0 ? lo + oc : p;
     p = zl >= nzl ? hi + oc : p;
     p = wall_lo ? vwall : p;
-    p = wall_hi ? vwall + 1 : p;
+    p = wall_hi ? vwall + 2 : p;
     return *p * (own ? inv : 1.0);
   }
+  // the same for the node pair (x, x+1), x even: one 16-byte load
+  __device__ __forceinline__ double2 center2(int z) const {
+    const int zl = z - z0;
+    const bool wall_lo = z <= 0, wall_hi = z >= nz - 1;
+    const bool own = !wall_lo && !wall_hi && zl >= 0 && zl < nzl;
+    const int zc = zl < 0 ? 0 : (zl >= nzl ? nzl - 1 : zl);
+    const double* p = work + (long long)zc * plane + oc;
+    p = zl < 0 ? lo + oc : p;
+    p = zl >= nzl ? hi + oc : p;
+    p = wall_lo ? vwall : p;
+    p = wall_hi ? vwall + 2 : p;
+    const double2 v = *reinterpret_cast<const double2*>(p);
+    const double sc = own ? inv : 1.0;
+    return make_double2(v.x * sc, v.y * sc);
+  }
 };
+
+// 16-byte store to an address that is only guaranteed to be 8-byte aligned (caller-bound field
+// arrays, ekpnp_bind_field): global_store_dwordx4 needs dword alignment only
+typedef double pair8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void store_pair(double* p, double a, double b) {
+  pair8 v = {a, b};
+  *reinterpret_cast<pair8*>(p) = v;
+}
 
 template <int PHI_ZCHUNK>
 __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, const int nrows) {
@@ -299,6 +324,80 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
   }
 }
 
+// The same kernel with TWO x nodes per lane (rows of a multiple of 128 nodes, i.e. every wave is
+// full): 16-byte loads and stores, and the x neighbours come out of the neighbouring lanes'
+// registers (the centre values the march holds anyway) instead of two more loads per node; only
+// lane 0 / lane 63 fetch the one value beyond the wave's 128 nodes.  Per 128 nodes and plane: 4 loads
+// and 4 stores instead of 10 and 8.  Same expressions, same bits as k_phi_efield.
+template <int PHI_ZCHUNK>
+__global__ void __launch_bounds__(256) k_phi_efield_x2(PArgs a, const int nxb, const int nrows) {
+  constexpr int RCHUNK = 64;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int r = slot / nxb, xb = slot - r * nxb;
+  const int row = ((r / RCHUNK) * 8 + xcd) * RCHUNK + r % RCHUNK;
+  if (row >= nrows) return;
+  const int x0 = (xb * blockDim.x + threadIdx.x) * 2;
+  if (x0 >= a.nx) return;  // whole waves only (nx % 128 == 0)
+  const int lane = threadIdx.x & 63;
+  const int y = row % a.ny;
+  const int zl0 = (row / a.ny) * PHI_ZCHUNK;
+  const int zl1 = min(zl0 + PHI_ZCHUNK, a.nzl);
+  const int yp1 = y + 1 == a.ny ? 0 : y + 1, ym1 = y == 0 ? a.ny - 1 : y - 1;
+  const long long oc = (long long)y * a.nx + x0;
+  const long long oym = (long long)ym1 * a.nx + x0, oyp = (long long)yp1 * a.nx + x0;
+  // the one node outside the wave's 128: to the left for lane 0, to the right for lane 63
+  const bool edge = lane == 0 || lane == 63;
+  const int xe = lane == 0 ? (x0 == 0 ? a.nx - 1 : x0 - 1) : (x0 + 2 == a.nx ? 0 : x0 + 2);
+  const long long oe = (long long)y * a.nx + xe;
+  const PhiColumn col{a.work, a.phi_lo, a.phi_hi, a.vwall, a.plane, oc, a.z0, a.nzl, a.nz, a.inv_nxny};
+  const double* __restrict__ w = a.work;
+  double* __restrict__ o_phi = a.fld[EKPNP_PHI];
+  double* __restrict__ o_ex = a.fld[EKPNP_EX];
+  double* __restrict__ o_ey = a.fld[EKPNP_EY];
+  double* __restrict__ o_ez = a.fld[EKPNP_EZ];
+
+  double2 pm = col.center2(a.z0 + zl0 - 1);
+  double2 p0 = col.center2(a.z0 + zl0);
+  const double* wz = w + (long long)zl0 * a.plane;
+  double2 nym = *reinterpret_cast<const double2*>(wz + oym), nyp = *reinterpret_cast<const double2*>(wz + oyp);
+  double ne = edge ? wz[oe] : 0.0;
+  double2 pp = col.center2(a.z0 + zl0 + 1);
+// (no unroll request: the lane exchange is a convergent operation, the optimizer declines)
+  for (int zl = zl0; zl < zl1; ++zl) {
+    const int z = a.z0 + zl;
+    // next plane's operands first (clamped to the chunk: the last iteration re-reads its own plane)
+    const int zn = zl + 1 < zl1 ? zl + 1 : zl;
+    const double* wn = w + (long long)zn * a.plane;
+    const double2 n_ym = *reinterpret_cast<const double2*>(wn + oym), n_yp = *reinterpret_cast<const double2*>(wn + oyp);
+    const double n_e = edge ? wn[oe] : 0.0;
+    const double2 n_pp = col.center2(a.z0 + zn + 1);
+
+    const bool wall = z == 0 || z == a.nz - 1;
+    const double vw = z == 0 ? a.voltage : a.voltage2;
+    const double es = wall ? vw : ne * a.inv_nxny;
+    const double from_left = __shfl_up(p0.y, 1, 64), from_right = __shfl_down(p0.x, 1, 64);
+    const double left = lane == 0 ? es : from_left;     // phi(x0 - 1)
+    const double right = lane == 63 ? es : from_right;  // phi(x0 + 2)
+    const double eym0 = wall ? vw : nym.x * a.inv_nxny, eym1 = wall ? vw : nym.y * a.inv_nxny;
+    const double eyp0 = wall ? vw : nyp.x * a.inv_nxny, eyp1 = wall ? vw : nyp.y * a.inv_nxny;
+    const long long i = (long long)zl * a.plane + oc;
+    store_pair(o_phi + i, p0.x, p0.y);
+    // the reference's expression 0.5*(a - b)/d (poisson.cu:53-55)
+    store_pair(o_ex + i, 0.5 * (left - p0.y) / a.dx, 0.5 * (p0.x - right) / a.dx);
+    store_pair(o_ey + i, 0.5 * (eym0 - eyp0) / a.dy, 0.5 * (eym1 - eyp1) / a.dy);
+    const double ez0 = 0.5 * (pm.x - pp.x) / a.dz, ez1 = 0.5 * (pm.y - pp.y) / a.dz;
+    // gpu_bc (poisson.cu:57-69): Ez(0) <- Ez(1), Ez(NZ-1) <- Ez(NZ-2)
+    if (!wall) store_pair(o_ez + i, ez0, ez1);
+    if (z == 1) store_pair(o_ez + i - a.plane, ez0, ez1);
+    if (z == a.nz - 2) store_pair(o_ez + i + a.plane, ez0, ez1);
+    pm = p0;
+    p0 = pp;
+    pp = n_pp;
+    nym = n_ym; nyp = n_yp; ne = n_e;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // z-slab version of the tridiagonal solve (no reference counterpart).
 // Rank r owns the unknown rows a..e of the global system (the interior planes of its slab,
@@ -350,13 +449,13 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __r
   if (md >= ms) return;
   const double dz2 = a.dz * a.dz;
   double2* s = a.spec + md + (long long)row_a * ms;  // local plane of the first unknown row
-  const double* cp = a.cprime + md;
+  const double b = mode_diag(md, a.ny, a.nxh, a.Lx, a.Ly, a.dz);
   const double* up = u + md;
-  double dr = 0.0, di = 0.0, p1r = 0.0, p1i = 0.0;
+  double dr = 0.0, di = 0.0, p1r = 0.0, p1i = 0.0, c = 0.0;
 #pragma unroll 8
   for (int k = 1; k <= m; ++k) {
     const double2 r = s[(long long)(k - 1) * ms];
-    const double c = cp[(long long)k * ms];
+    c = 1.0 / (b - c);  // c'_k: the table's recurrence, in registers (k_build_cprime)
     const double uk = up[(long long)(k - 1) * ms];
     const double rr = dz2 * r.x, ri = dz2 * r.y;
     p1r += uk * rr;
@@ -432,8 +531,9 @@ __global__ void k_slab_reduce_correct(PArgs a, int rank, int nranks, int row_a, 
   // back substitution of A x = r - g_lo e_1 - g_hi e_m; d' is recomputed block by block from the
   // checkpoints stage 1 left in every TRI_BS-th row (as in k_tridiag)
   double2* s = a.spec + md + (long long)row_a * ms;
-  const double* cp = a.cprime + md;
-  const double* wp = w + md;
+  const double* cp = a.cprime + md;  // table row k = c'_k; only the rows below the blocks are read
+  const double* wp = w + md;         // table row k-1 = w_k; likewise
+  const double b = mode_diag(md, a.ny, a.nxh, a.Lx, a.Ly, a.dz);
   const double dz2 = a.dz * a.dz;
   double xr = 0.0, xi = 0.0;
   for (int khi = m; khi >= 1;) {
@@ -441,20 +541,26 @@ __global__ void k_slab_reduce_correct(PArgs a, int rank, int nranks, int row_a, 
     double2 d[TRI_BS];
     double c[TRI_BS], wv[TRI_BS];
     double2 prev = make_double2(0.0, 0.0);
-    if (klo > 1) prev = s[(long long)(klo - 2) * ms];
+    double cprev = 0.0, wprev = 0.0;
+    if (klo > 1) {
+      prev = s[(long long)(klo - 2) * ms];
+      cprev = cp[(long long)(klo - 1) * ms];
+      wprev = wp[(long long)(klo - 2) * ms];
+    }
 #pragma unroll
     for (int i = 0; i < TRI_BS; ++i) {
       const int k = klo + i;
-      if (k <= khi) {
-        d[i] = s[(long long)(k - 1) * ms];
-        c[i] = cp[(long long)k * ms];
-        wv[i] = wp[(long long)(k - 1) * ms];
-      }
+      if (k <= khi) d[i] = s[(long long)(k - 1) * ms];
     }
 #pragma unroll
     for (int i = 0; i < TRI_BS; ++i) {
       const int k = klo + i;
       if (k <= khi) {
+        // c'_k and w_k by the recurrences that filled the tables (k_build_cprime, k_slab_unit_response)
+        cprev = 1.0 / (b - cprev);
+        c[i] = cprev;
+        wprev = ((k == 1 ? 1.0 : 0.0) - wprev) * cprev;
+        wv[i] = wprev;
         if (i != TRI_BS - 1) {
           d[i].x = (dz2 * d[i].x - prev.x) * c[i];
           d[i].y = (dz2 * d[i].y - prev.y) * c[i];
@@ -556,12 +662,19 @@ void launch_tridiag(Ctx& c) {
 
 void launch_phi_efield(Ctx& c) {
   PArgs a = c.pargs();
-  const int bx = c.p.nx >= 256 ? 256 : 64;
-  const int nxb = (c.p.nx + bx - 1) / bx;
   const bool small = c.nloc < (size_t)2 * 1024 * 1024;
   const int zchunk = small ? 1 : PHI_ZCHUNK_LARGE;
   const int nrows = c.p.ny * ((c.nzl + zchunk - 1) / zchunk);
   const long long per_xcd = ((long long)nrows + 8 * 64 - 1) / (8 * 64) * 64;
+  static const bool no_x2 = std::getenv("EKPNP_PHI_X1") != nullptr;  // A/B knob: the one-node-per-lane kernel everywhere
+  if (!small && !no_x2 && c.p.nx % 128 == 0) {  // whole waves of node pairs
+    const int bx = c.p.nx >= 512 ? 256 : c.p.nx / 2;  // threads per block, each two nodes
+    const int nxb = c.p.nx / (2 * bx);
+    hipLaunchKernelGGL(k_phi_efield_x2<PHI_ZCHUNK_LARGE>, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
+    return;
+  }
+  const int bx = c.p.nx >= 256 ? 256 : 64;
+  const int nxb = (c.p.nx + bx - 1) / bx;
   if (small)
     hipLaunchKernelGGL(k_phi_efield<1>, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
   else

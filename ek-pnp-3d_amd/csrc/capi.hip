@@ -22,6 +22,14 @@ static thread_local std::string g_create_err;
       return e_ == hipErrorOutOfMemory ? EKPNP_ERR_NOMEM : EKPNP_ERR_HIP;                       \
     }                                                                                           \
   } while (0)
+// after the launches of an entry point: the first rejected launch, by kernel name
+#define LAUNCHCHK(ctx)                                                                          \
+  do {                                                                                          \
+    if (take_launch_error(ctx) != hipSuccess) {                                                 \
+      if ((ctx).err.empty()) (ctx).err = "a kernel launch failed";                              \
+      return EKPNP_ERR_HIP;                                                                     \
+    }                                                                                           \
+  } while (0)
 
 #define FFTCHK(ctx, call)                                                                       \
   do {                                                                                          \
@@ -40,6 +48,37 @@ static int fail(Ctx& c, const char* msg) {
   c.err = msg;
   return EKPNP_ERR_INVALID;
 }
+
+namespace ekpnp {
+void note_launch(Ctx& c, const char* kernel) {
+  static const bool debug_sync = std::getenv("EKPNP_DEBUG_SYNC") != nullptr;
+  // fault injection for the tests of this very path: EKPNP_INJECT_LAUNCH_FAILURE=<kernel name>
+  static const char* const inject = std::getenv("EKPNP_INJECT_LAUNCH_FAILURE");
+  hipError_t e = hipGetLastError();
+  if (inject && e == hipSuccess && std::strcmp(inject, kernel) == 0) e = hipErrorLaunchFailure;
+  if (e == hipSuccess && debug_sync) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c.stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) e = hipStreamSynchronize(c.stream);
+  }
+  if (e != hipSuccess && c.launch_err == hipSuccess) {
+    c.launch_err = e;
+    c.launch_what = kernel;
+  }
+}
+hipError_t take_launch_error(Ctx& c) {
+  hipError_t e = c.launch_err;
+  if (e != hipSuccess) {
+    c.err = std::string("kernel ") + (c.launch_what ? c.launch_what : "?") + ": " + hipGetErrorString(e);
+    c.launch_err = hipSuccess;
+    c.launch_what = nullptr;
+    (void)hipGetLastError();
+    return e;
+  }
+  return hipGetLastError();
+}
+}  // namespace ekpnp
+
+extern "C" int ekpnp_debug_sync_enabled(void) { return std::getenv("EKPNP_DEBUG_SYNC") != nullptr; }
 
 static void drop_graph(Ctx& c) {
   if (c.graph2) { (void)hipGraphExecDestroy(c.graph2); c.graph2 = nullptr; }
@@ -343,7 +382,7 @@ extern "C" int ekpnp_set_stream(ekpnp_ctx* ctx, void* s) {
 extern "C" int ekpnp_synchronize(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   HIPCHK(c, hipStreamSynchronize(c.stream));
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -455,7 +494,7 @@ static int poisson_single(Ctx& c) {
   launch_tridiag(c);
   FFTCHK(c, hipfftExecZ2D(c.plan_inv, (hipfftDoubleComplex*)c.spec, c.work));
   launch_phi_efield(c);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -487,7 +526,7 @@ extern "C" int ekpnp_init_fields(ekpnp_ctx* ctx) {  // gpu_initialization, LBM.c
   NEEDCTX(ctx);
   c.rhs_ready = false;
   launch_init_fields(c);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -502,7 +541,7 @@ extern "C" int ekpnp_pbe_concentrations(ekpnp_ctx* ctx) {  // gpu_PBE, LBM.cu:13
   NEEDCTX(ctx);
   c.rhs_ready = false;
   launch_pbe(c);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -510,7 +549,7 @@ extern "C" int ekpnp_pbe_relax(ekpnp_ctx* ctx) {  // gpu_PBE_phi + phi_old updat
   NEEDCTX(ctx);
   if (!c.phi_old) return fail(c, "ekpnp_pbe_relax without ekpnp_pbe_begin");
   launch_pbe_relax(c, c.phi_old, c.p.PB_omega);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -534,7 +573,7 @@ extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
   }
   int rc2 = ekpnp_pbe_end(ctx);
   if (rc == EKPNP_OK) rc = rc2;
-  if (rc == EKPNP_OK) HIPCHK(c, hipGetLastError());
+  if (rc == EKPNP_OK) LAUNCHCHK(c);
   return rc;
 }
 
@@ -592,7 +631,7 @@ extern "C" int ekpnp_init_equilibrium(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   launch_init_equilibrium(c);
   c.streamed_state = true;
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -675,7 +714,7 @@ extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
   }
   finish_collide(c);
   if (c.inplace) launch_ghost_wrap(c);  // z-periodic ghost loop of gpu_stream, LBM.cu:1972,1975 (by index otherwise)
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -813,7 +852,7 @@ extern "C" int ekpnp_halo_pack(ekpnp_ctx* ctx) {
     // between the boundary and the interior call the fresh planes are in the NEXT buffer
     launch_halo_pack(c, c.collide_phase == 1 ? (c.cur ^ 1) : c.cur);
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -822,7 +861,7 @@ extern "C" int ekpnp_halo_unpack(ekpnp_ctx* ctx) {
   if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
   if (c.collide_phase != 0) return fail(c, "ekpnp_halo_unpack before ekpnp_collide_interior_planes");
   launch_halo_unpack(c);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -843,7 +882,7 @@ extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
   if (c.z0 != 0) launch_collide_bulk(c, lo, 0, 1);
   if (c.z0 + c.nzl != c.p.nz) launch_collide_bulk(c, hi, c.nzl - 1, c.nzl);
   c.collide_phase = 1;
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -875,7 +914,7 @@ extern "C" int ekpnp_collide_interior_planes(ekpnp_ctx* ctx) {
   finish_collide(c);
   if (c.inplace) launch_unstage(c);  // the two staged planes take their place in the shifted lattice
   c.collide_phase = 0;
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -893,7 +932,7 @@ extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
   c.rhs_ready = false;
   FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.work, (hipfftDoubleComplex*)c.spec));
   launch_slab_thomas_local(c);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -911,7 +950,7 @@ extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) {
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   launch_slab_reduce_correct(c);
   FFTCHK(c, hipfftExecZ2D(c.plan_inv, (hipfftDoubleComplex*)c.spec, c.work));
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -919,7 +958,7 @@ extern "C" int ekpnp_phi_halo_pack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
   launch_phi_halo_pack(c);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }
 
@@ -927,6 +966,6 @@ extern "C" int ekpnp_poisson_stage3(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   launch_phi_efield(c);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return EKPNP_OK;
 }

@@ -85,21 +85,27 @@ void launch_current(Ctx& c, double* scratch /* DIAG_BLOCKS + 1 doubles */) {
   const int nb = (int)((c.plane + 255) / 256 < DIAG_BLOCKS ? (c.plane + 255) / 256 : DIAG_BLOCKS);
   hipLaunchKernelGGL(k_wall_current, dim3(nb), dim3(256), 0, c.stream, c.fld[EKPNP_C], c.fld[EKPNP_CN], c.fld[EKPNP_EZ], (long long)c.plane,
                      c.nzl, scratch);
+  note_launch(c, "k_wall_current");
   hipLaunchKernelGGL((k_final<false>), dim3(1), dim3(256), 0, c.stream, scratch, nb, scratch + DIAG_BLOCKS);
+  note_launch(c, "k_final<false>");
 }
 
 void launch_umax(Ctx& c, double* scratch) {
   const long long n = (long long)c.nloc;
   const int nb = (int)((n + 255) / 256 < DIAG_BLOCKS ? (n + 255) / 256 : DIAG_BLOCKS);
   hipLaunchKernelGGL(k_max_uz, dim3(nb), dim3(256), 0, c.stream, c.fld[EKPNP_UZ], n, scratch);
+  note_launch(c, "k_max_uz");
   hipLaunchKernelGGL((k_final<true>), dim3(1), dim3(256), 0, c.stream, scratch, nb, scratch + DIAG_BLOCKS);
+  note_launch(c, "k_final<true>");
 }
 
 void launch_max_abs_diff(Ctx& c, const double* p, const double* q, double* scratch) {
   const long long n = (long long)c.nloc;
   const int nb = (int)((n + 255) / 256 < DIAG_BLOCKS ? (n + 255) / 256 : DIAG_BLOCKS);
   hipLaunchKernelGGL(k_max_abs_diff, dim3(nb), dim3(256), 0, c.stream, p, q, n, scratch);
+  note_launch(c, "k_max_abs_diff");
   hipLaunchKernelGGL((k_final<true>), dim3(1), dim3(256), 0, c.stream, scratch, nb, scratch + DIAG_BLOCKS);
+  note_launch(c, "k_final<true>");
 }
 
 // plain contiguous copy, 16 bytes per lane (the shape tools/stream_probe.hip calls "copy 16B/lane")
@@ -111,6 +117,7 @@ __global__ void k_copy16(const double2* __restrict__ src, double2* __restrict__ 
 void launch_copy16(Ctx& c, const void* src, void* dst, size_t bytes) {
   const size_t n = bytes / sizeof(double2);
   hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, (const double2*)src, (double2*)dst, n);
+  note_launch(c, "k_copy16");
 }
 
 }  // namespace ekpnp

@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -200,6 +201,9 @@ struct Ctx {
   bool plans = false;
   double t = 0.0;
   size_t bytes = 0;
+  // first kernel launch that failed since the last check (note_launch / take_launch_error)
+  hipError_t launch_err = hipSuccess;
+  const char* launch_what = nullptr;
   // kernel timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -210,6 +214,16 @@ struct Ctx {
   KArgs kargs() const;
   PArgs pargs() const;
 };
+
+// Called after EVERY kernel launch of the library: a launch that the runtime rejects (bad grid,
+// missing code object ...) is recorded with the kernel's name instead of surfacing, nameless, at the
+// end of the entry point.  With EKPNP_DEBUG_SYNC set in the environment the stream is also
+// synchronised after each launch, so that a fault inside a kernel is reported against that kernel
+// (debug runs only: it serialises host and device).
+void note_launch(Ctx& c, const char* kernel);
+// The status the entry points return after their launches: the recorded launch error (its message
+// names the kernel) or whatever hipGetLastError() holds.  Clears both.
+hipError_t take_launch_error(Ctx& c);
 
 // slab_team.hip: the reference's verbs on a slab context whose team moves the halos itself
 // (ekpnp_slab_attach_comm).  Each returns EKPNP_ERR_INVALID with a message if the context's team
@@ -228,6 +242,18 @@ bool team_is_group(const Ctx&);  // the context is a member of an in-process ekp
 struct TextIoArgs { const char* path; int append; double time; int first; int kind; };  // kind 0 Tecplot, 1 data_end
 int io_write_text_part(Ctx&, const TextIoArgs&);
 int io_read_data_part(Ctx&, const char* path, double* time);
+
+// full checkpoint (io.hip), pieces shared with the group variant in slab_team.hip
+struct CkptHeader {
+  char magic[8];
+  int32_t nx, ny, nz, z0, nzl, nfields, nl, streamed_state, with_ghosts, pad_[3];
+  double time;
+};
+int io_ckpt_write_header(Ctx&, FILE*, int z0, int nzl, int with_ghosts, double time);
+int io_ckpt_check_header(Ctx&, const CkptHeader&, int z0, int nzl);
+int io_ckpt_fields(Ctx&, FILE*, int field, int dir);              // dir 0: device -> file, 1: file -> device
+int io_ckpt_populations(Ctx&, FILE*, int lattice, int with_ghosts, int dir);
+void io_ckpt_finish_load(Ctx&, const CkptHeader&);
 
 }  // namespace ekpnp
 

@@ -90,7 +90,10 @@ int main(int argc, char* argv[]) {
       std::fprintf(stderr,
                    "usage: ekpnp_main [--nx N --ny N --nz N] [--steps N] [--nsave N] [--print-current N] [--read-previous 0|1|2]\n"
                    "                  [--binary-state 0|1] [--gpus N [--transport auto|rccl|copy] [--devices d0,d1,...]]\n"
-                   "                  [--lattices 1|3|4] [--exf F --uw U --chargeinf C --Ra R --TH T] [--out DIR]\n");
+                   "                  [--lattices 1|3|4] [--exf F --uw U --chargeinf C --Ra R --TH T] [--out DIR]\n"
+                   "  --read-previous 1: restart from data_end.dat (%%10.6f text, the reference's); 2: from data_end.bin (--binary-state 1,\n"
+                   "  the 11 fields as raw FP64).  Both restarts are the reference's (main.cu:161-175): the populations are rebuilt as the\n"
+                   "  EQUILIBRIUM of the fields, so a restarted run is not the bitwise continuation of the interrupted one.\n");
       return 2;
     }
   }

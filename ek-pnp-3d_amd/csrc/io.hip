@@ -49,6 +49,7 @@ extern "C" int ekpnp_current(ekpnp_ctx* ctx, double* I) {
     int rc = need_scratch(c);
     if (rc) return rc;
     launch_current(c, c.diag);
+    if (take_launch_error(c) != hipSuccess) return EKPNP_ERR_HIP;
     double s = 0.0;
     HIPCHK(c, hipMemcpyAsync(&s, c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream));
     HIPCHK(c, hipStreamSynchronize(c.stream));
@@ -63,6 +64,7 @@ extern "C" int ekpnp_umax(ekpnp_ctx* ctx, double* umax) {
   int rc = need_scratch(c);
   if (rc) return rc;
   launch_umax(c, c.diag);
+  if (take_launch_error(c) != hipSuccess) return EKPNP_ERR_HIP;
   double s = 0.0;
   HIPCHK(c, hipMemcpyAsync(&s, c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(c, hipStreamSynchronize(c.stream));
@@ -267,6 +269,109 @@ extern "C" int ekpnp_read_state(ekpnp_ctx* ctx, const char* path, double* time) 
   *time = h.time;
   c.t = h.time;
   c.rhs_ready = false;
+  return EKPNP_OK;
+}
+
+// ---- full checkpoint: fields AND populations (no reference counterpart; SURVEY.md §5 "checkpoint /
+// resume ... if built later, binary FP64").  Unlike the restart above, loading it continues the
+// interrupted run bit for bit: the post-collision populations of all lattices travel too.
+// Layout: 64-byte header, the 11 fields (owned planes), then per lattice the owned population
+// planes in the library's tiled layout [z][y][x/64][27][64] (ekpnp_internal.h); a slab context on
+// its own also stores its two ghost planes (flag with_ghosts) so that a per-rank file is
+// self-contained.  A whole-lattice file (z0 = 0, nz_local = nz, no ghosts) is what a single context
+// and ekpnp_group_save_checkpoint write; either can load it, in two-buffer or in-place mode.
+namespace ekpnp {
+static_assert(sizeof(CkptHeader) == 64, "checkpoint header layout");
+
+int io_ckpt_write_header(Ctx& c, FILE* f, int z0, int nzl, int with_ghosts, double time) {
+  CkptHeader h{};
+  std::memcpy(h.magic, "EKPNPCK1", 8);
+  h.nx = c.p.nx; h.ny = c.p.ny; h.nz = c.p.nz; h.z0 = z0; h.nzl = nzl; h.nfields = EKPNP_NFIELDS;
+  h.nl = c.p.n_lattices; h.streamed_state = c.streamed_state ? 1 : 0; h.with_ghosts = with_ghosts;
+  h.time = time;
+  return std::fwrite(&h, sizeof h, 1, f) == 1 ? EKPNP_OK : fail(c, "write error on checkpoint file");
+}
+
+// device memory <-> file through a bounce buffer; dir 0: device -> file, 1: file -> device
+int io_stream_device(Ctx& c, FILE* f, double* dev, size_t n, int dir) {
+  static thread_local std::vector<double> buf;
+  if (buf.size() < STATE_CHUNK) buf.resize(STATE_CHUNK);
+  for (size_t o = 0; o < n; o += STATE_CHUNK) {
+    const size_t m = n - o < STATE_CHUNK ? n - o : STATE_CHUNK;
+    if (dir == 0) {
+      HIPCHK(c, hipMemcpy(buf.data(), dev + o, m * sizeof(double), hipMemcpyDeviceToHost));
+      if (std::fwrite(buf.data(), sizeof(double), m, f) != m) return fail(c, "write error on checkpoint file");
+    } else {
+      if (std::fread(buf.data(), sizeof(double), m, f) != m) return fail(c, "checkpoint file is shorter than the lattice");
+      HIPCHK(c, hipMemcpy(dev + o, buf.data(), m * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  return EKPNP_OK;
+}
+
+int io_ckpt_fields(Ctx& c, FILE* f, int field, int dir) { return io_stream_device(c, f, c.fld[field], c.nloc, dir); }
+
+// owned planes zg = 1..nzl of lattice l's current state (with_ghosts: zg = 0..nzl+1)
+int io_ckpt_populations(Ctx& c, FILE* f, int l, int with_ghosts, int dir) {
+  double* base = c.cur_base(l);
+  if (!base) return fail(c, "lattice not allocated");
+  return with_ghosts ? io_stream_device(c, f, base, (size_t)(c.nzl + 2) * c.pplane, dir)
+                     : io_stream_device(c, f, base + c.pplane, (size_t)c.nzl * c.pplane, dir);
+}
+
+int io_ckpt_check_header(Ctx& c, const CkptHeader& h, int z0, int nzl) {
+  if (std::memcmp(h.magic, "EKPNPCK1", 8) != 0) return fail(c, "not an EKPNPCK1 checkpoint file");
+  if (h.nx != c.p.nx || h.ny != c.p.ny || h.nz != c.p.nz || h.nfields != EKPNP_NFIELDS || h.nl != c.p.n_lattices)
+    return fail(c, "checkpoint was written for a different lattice");
+  if (h.z0 != z0 || h.nzl != nzl) return fail(c, "checkpoint holds other planes than this context / group owns");
+  return EKPNP_OK;
+}
+
+void io_ckpt_finish_load(Ctx& c, const CkptHeader& h) {
+  c.streamed_state = h.streamed_state != 0;
+  c.t = h.time;
+  c.rhs_ready = false;
+  c.collide_phase = 0;
+}
+}  // namespace ekpnp
+
+extern "C" int ekpnp_save_checkpoint(ekpnp_ctx* ctx, const char* path) {
+  NEEDCTX(ctx);
+  if (!path) return fail(c, "NULL path");
+  if (c.collide_phase != 0) return fail(c, "ekpnp_save_checkpoint between the boundary and the interior collide call");
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return fail(c, "cannot open checkpoint file");
+  const int ghosts = c.slab ? 1 : 0;
+  int rc = io_ckpt_write_header(c, f, c.z0, c.nzl, ghosts, c.t);
+  for (int i = 0; rc == EKPNP_OK && i < EKPNP_NFIELDS; ++i) rc = io_ckpt_fields(c, f, i, 0);
+  for (int l = 0; rc == EKPNP_OK && l < c.p.n_lattices; ++l) rc = io_ckpt_populations(c, f, l, ghosts, 0);
+  if (std::fclose(f) != 0 && rc == EKPNP_OK) rc = fail(c, "write error on checkpoint file");
+  return rc;
+}
+
+extern "C" int ekpnp_load_checkpoint(ekpnp_ctx* ctx, const char* path, double* time) {
+  NEEDCTX(ctx);
+  if (!path) return fail(c, "NULL path");
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(c, "cannot open checkpoint file");
+  CkptHeader h{};
+  int rc = std::fread(&h, sizeof h, 1, f) == 1 ? io_ckpt_check_header(c, h, c.z0, c.nzl) : fail(c, "not an EKPNPCK1 checkpoint file");
+  if (rc == EKPNP_OK && c.slab && c.nranks > 1 && !h.with_ghosts)
+    rc = fail(c, "a slab context loads its own per-rank checkpoint (with ghost planes); whole-lattice files go through ekpnp_group_load_checkpoint");
+  if (rc == EKPNP_OK && !c.slab && h.with_ghosts) rc = fail(c, "this is a slab's per-rank checkpoint");
+  for (int i = 0; rc == EKPNP_OK && i < EKPNP_NFIELDS; ++i) rc = io_ckpt_fields(c, f, i, 1);
+  for (int l = 0; rc == EKPNP_OK && l < c.p.n_lattices; ++l) rc = io_ckpt_populations(c, f, l, h.with_ghosts, 1);
+  std::fclose(f);
+  if (rc) return rc;
+  io_ckpt_finish_load(c, h);
+  if (!h.with_ghosts) {  // gpu_stream's z wrap (LBM.cu:1972,1975): ghost planes <- opposite wall planes
+    launch_ghost_wrap(c);
+    if (take_launch_error(c) != hipSuccess) return EKPNP_ERR_HIP;
+    HIPCHK(c, hipStreamSynchronize(c.stream));
+  }
+  if (time) *time = h.time;
   return EKPNP_OK;
 }
 

@@ -553,16 +553,19 @@ static inline dim3 grid1d(long long n, int b) { return dim3((unsigned)((n + b - 
 void launch_init_fields(Ctx& c) {
   KArgs a = c.kargs();
   hipLaunchKernelGGL(k_init_fields, grid1d((long long)c.nloc, 256), dim3(256), 0, c.stream, a, c.p.voltage, c.p.Lz, c.p.dz);
+  note_launch(c, "k_init_fields");
 }
 
 void launch_pbe(Ctx& c) {
   hipLaunchKernelGGL(k_pbe, grid1d((long long)c.nloc, 256), dim3(256), 0, c.stream, c.fld[EKPNP_C], c.fld[EKPNP_CN], c.fld[EKPNP_PHI],
                      (long long)c.nloc, c.p.chargeinf, c.p.electron, c.p.kB, c.p.roomT);
+  note_launch(c, "k_pbe");
 }
 
 void launch_pbe_relax(Ctx& c, double* phi_old, double omega) {
   hipLaunchKernelGGL(k_pbe_relax, grid1d((long long)c.nloc, 256), dim3(256), 0, c.stream, c.fld[EKPNP_PHI], phi_old, (long long)c.nloc,
                      omega);
+  note_launch(c, "k_pbe_relax");
 }
 
 void launch_init_equilibrium(Ctx& c) {
@@ -571,9 +574,9 @@ void launch_init_equilibrium(Ctx& c) {
   for (int l = 0; l < MAXL; ++l) a.B[l] = c.cur_base(l);
   dim3 g = grid1d((long long)c.nloc, 128), b(128);
   switch (c.p.n_lattices) {
-    case 1: hipLaunchKernelGGL(k_init_equilibrium<1>, g, b, 0, c.stream, a); break;
-    case 3: hipLaunchKernelGGL(k_init_equilibrium<3>, g, b, 0, c.stream, a); break;
-    default: hipLaunchKernelGGL(k_init_equilibrium<4>, g, b, 0, c.stream, a); break;
+    case 1: hipLaunchKernelGGL(k_init_equilibrium<1>, g, b, 0, c.stream, a); note_launch(c, "k_init_equilibrium<1>"); break;
+    case 3: hipLaunchKernelGGL(k_init_equilibrium<3>, g, b, 0, c.stream, a); note_launch(c, "k_init_equilibrium<3>"); break;
+    default: hipLaunchKernelGGL(k_init_equilibrium<4>, g, b, 0, c.stream, a); note_launch(c, "k_init_equilibrium<4>"); break;
   }
 }
 
@@ -591,6 +594,7 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
     hipLaunchKernelGGL((k_collide_bulk<NL, false>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
   else
     hipLaunchKernelGGL((k_collide_bulk<NL, true>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
+  note_launch(c, "k_collide_bulk");
 }
 
 void launch_collide_bulk(Ctx& c, int zl_begin, int zl_end) { launch_collide_bulk(c, c.kargs(), zl_begin, zl_end); }
@@ -610,6 +614,7 @@ static void wall_dispatch(Ctx& c, const KArgs& a, int first_wall, int nwalls, hi
     hipLaunchKernelGGL((k_collide_wall<NL, false>), g, b, 0, stream, a, first_wall);
   else
     hipLaunchKernelGGL((k_collide_wall<NL, true>), g, b, 0, stream, a, first_wall);
+  note_launch(c, "k_collide_wall");
 }
 
 void launch_collide_walls(Ctx& c, hipStream_t stream, bool want_lower, bool want_upper) {
@@ -633,23 +638,27 @@ static dim3 halo_grid(const Ctx& c) { return dim3((unsigned)((c.p.nx + 255) / 25
 void launch_ghost_wrap(Ctx& c) {
   double* p[MAXL] = {c.cur_base(0), c.cur_base(1), c.cur_base(2), c.cur_base(3)};
   hipLaunchKernelGGL(k_ghost_wrap, halo_grid(c), dim3(256), 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, pop_geom(c));
+  note_launch(c, "k_ghost_wrap");
 }
 
 void launch_halo_pack(Ctx& c, int buffer) {
   double** p = c.pop[buffer];
   hipLaunchKernelGGL(k_halo_pack, halo_grid(c), dim3(256), 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, pop_geom(c), c.halo[0],
                      c.halo[1]);
+  note_launch(c, "k_halo_pack");
 }
 
 void launch_halo_unpack(Ctx& c) {
   double* p[MAXL] = {c.cur_base(0), c.cur_base(1), c.cur_base(2), c.cur_base(3)};
   hipLaunchKernelGGL(k_halo_unpack, halo_grid(c), dim3(256), 0, c.stream, p[0], p[1], p[2], p[3], c.p.n_lattices, pop_geom(c), c.halo[2],
                      c.halo[3]);
+  note_launch(c, "k_halo_unpack");
 }
 
 void launch_halo_pack_stage(Ctx& c) {
   hipLaunchKernelGGL(k_halo_pack_stage, halo_grid(c), dim3(256), 0, c.stream, c.stage[0], c.stage[1], c.stage[2], c.stage[3],
                      c.p.n_lattices, pop_geom(c), c.halo[0], c.halo[1]);
+  note_launch(c, "k_halo_pack_stage");
 }
 
 void launch_unstage(Ctx& c) {
@@ -657,6 +666,7 @@ void launch_unstage(Ctx& c) {
   dim3 g((unsigned)((c.pplane + 255) / 256)), b(256);
   hipLaunchKernelGGL(k_unstage, g, b, 0, c.stream, p[0], p[1], p[2], p[3], c.stage[0], c.stage[1], c.stage[2], c.stage[3], c.p.n_lattices,
                      (long long)c.pplane, c.nzl);
+  note_launch(c, "k_unstage");
 }
 
 }  // namespace ekpnp

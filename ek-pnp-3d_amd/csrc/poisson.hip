@@ -605,23 +605,26 @@ int build_cprime(Ctx& c) {
   const int rows_nz = !c.slab ? c.p.nz : c.nzl + 2;
   hipLaunchKernelGGL(k_build_cprime, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.p.nx, c.p.ny, rows_nz, c.nxh, c.p.Lx,
                      c.p.Ly, c.p.dz, c.slab ? 1 : TRI_BS);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hipfail("k_build_cprime launch", e);
+  note_launch(c, "k_build_cprime");
+  if (take_launch_error(c) != hipSuccess) return EKPNP_ERR_HIP;  // message names the kernel
+  hipError_t e = hipSuccess;
   if (c.slab) {
     const bool edge_rank = (c.rank == 0 || c.rank == c.nranks - 1);
     hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.slab_m, nm, c.slab_u,
                        edge_rank ? c.u1um[0] : c.u1um[1], c.slab_w);
-    if ((e = hipGetLastError()) != hipSuccess) return hipfail("k_slab_unit_response launch", e);
+    note_launch(c, "k_slab_unit_response");
+    if (take_launch_error(c) != hipSuccess) return EKPNP_ERR_HIP;
     // (u_1, u_m) of the other slab type, through a scratch vector (set-up only)
     const int m_other = edge_rank ? c.nzl : c.nzl - 1;
     double* tmp = nullptr;
     if ((e = hipMalloc((void**)&tmp, (size_t)m_other * nm * sizeof(double))) != hipSuccess) return hipfail("scratch allocation for the slab unit response", e);
     hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, m_other, nm, tmp,
                        edge_rank ? c.u1um[1] : c.u1um[0], (double*)nullptr);
-    e = hipGetLastError();
+    note_launch(c, "k_slab_unit_response");
+    const hipError_t el = take_launch_error(c);
     const hipError_t es = hipStreamSynchronize(c.stream);
     const hipError_t ef = hipFree(tmp);
-    if (e != hipSuccess) return hipfail("k_slab_unit_response launch", e);
+    if (el != hipSuccess) return EKPNP_ERR_HIP;
     if (es != hipSuccess) return hipfail("slab unit response", es);
     if (ef != hipSuccess) return hipfail("hipFree of the unit-response scratch", ef);
   }
@@ -632,6 +635,7 @@ void launch_slab_thomas_local(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
   hipLaunchKernelGGL(k_slab_thomas_local, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, c.edge_local);
+  note_launch(c, "k_slab_thomas_local");
 }
 
 void launch_slab_reduce_correct(Ctx& c) {
@@ -639,16 +643,19 @@ void launch_slab_reduce_correct(Ctx& c) {
   const int nm = c.p.ny * c.nxh;
   hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.slab_row_a, c.slab_m,
                      c.edge_all, c.u1um[0], c.u1um[1], c.slab_w);
+  note_launch(c, "k_slab_reduce_correct");
 }
 
 void launch_phi_halo_pack(Ctx& c) {
   PArgs a = c.pargs();
   hipLaunchKernelGGL(k_phi_halo_pack, dim3((unsigned)((c.plane + 255) / 256)), dim3(256), 0, c.stream, a, c.phi_halo[0], c.phi_halo[1]);
+  note_launch(c, "k_phi_halo_pack");
 }
 
 void launch_poisson_rhs(Ctx& c) {
   PArgs a = c.pargs();
   hipLaunchKernelGGL(k_poisson_rhs, dim3((unsigned)((c.nloc + 255) / 256)), dim3(256), 0, c.stream, a);
+  note_launch(c, "k_poisson_rhs");
 }
 
 void launch_tridiag(Ctx& c) {
@@ -658,6 +665,7 @@ void launch_tridiag(Ctx& c) {
     hipLaunchKernelGGL(k_tridiag_pcr64, dim3((nm + 3) / 4), dim3(256), 0, c.stream, a);
   else
     hipLaunchKernelGGL(k_tridiag, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a);
+  note_launch(c, "k_tridiag");
 }
 
 void launch_phi_efield(Ctx& c) {
@@ -671,6 +679,7 @@ void launch_phi_efield(Ctx& c) {
     const int bx = c.p.nx >= 512 ? 256 : c.p.nx / 2;  // threads per block, each two nodes
     const int nxb = c.p.nx / (2 * bx);
     hipLaunchKernelGGL(k_phi_efield_x2<PHI_ZCHUNK_LARGE>, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
+    note_launch(c, "k_phi_efield_x2<PHI_ZCHUNK_LARGE>");
     return;
   }
   const int bx = c.p.nx >= 256 ? 256 : 64;
@@ -679,6 +688,7 @@ void launch_phi_efield(Ctx& c) {
     hipLaunchKernelGGL(k_phi_efield<1>, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
   else
     hipLaunchKernelGGL(k_phi_efield<PHI_ZCHUNK_LARGE>, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
+  note_launch(c, "k_phi_efield");
 }
 
 }  // namespace ekpnp

@@ -901,3 +901,64 @@ extern "C" int ekpnp_group_read_state(ekpnp_group* g, const char* path, double* 
   *time = h.time;
   return EKPNP_OK;
 }
+
+// whole-lattice EKPNPCK1 checkpoint (fields + post-collision populations): the file a single
+// context writes with ekpnp_save_checkpoint; loading continues the run bit for bit
+extern "C" int ekpnp_group_save_checkpoint(ekpnp_group* g, const char* path) {
+  NEEDGROUP(g);
+  if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
+  int rc = team_synchronize(T);
+  if (rc) return rc;
+  FILE* f = std::fopen(path, "wb");
+  if (!f) { T.err = "cannot open checkpoint file"; return EKPNP_ERR_INVALID; }
+  const int n = (int)T.m.size();
+  rc = io_ckpt_write_header(S(T, 0), f, 0, S(T, 0).p.nz, 0, S(T, 0).t);
+  if (rc) T.err = S(T, 0).err;
+  for (int id = 0; rc == EKPNP_OK && id < EKPNP_NFIELDS; ++id)
+    for (int i = 0; rc == EKPNP_OK && i < n; ++i)
+      if ((rc = use(T, i)) == EKPNP_OK && (rc = io_ckpt_fields(S(T, i), f, id, 0))) T.err = S(T, i).err;
+  for (int l = 0; rc == EKPNP_OK && l < S(T, 0).p.n_lattices; ++l)
+    for (int i = 0; rc == EKPNP_OK && i < n; ++i)
+      if ((rc = use(T, i)) == EKPNP_OK && (rc = io_ckpt_populations(S(T, i), f, l, 0, 0))) T.err = S(T, i).err;
+  if (std::fclose(f) != 0 && rc == EKPNP_OK) { T.err = "write error on checkpoint file"; rc = EKPNP_ERR_INVALID; }
+  return rc;
+}
+
+extern "C" int ekpnp_group_load_checkpoint(ekpnp_group* g, const char* path, double* time) {
+  NEEDGROUP(g);
+  if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
+  int rc = team_synchronize(T);
+  if (rc) return rc;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { T.err = "cannot open checkpoint file"; return EKPNP_ERR_INVALID; }
+  const int n = (int)T.m.size();
+  CkptHeader h{};
+  if (std::fread(&h, sizeof h, 1, f) != 1) { std::fclose(f); T.err = "not an EKPNPCK1 checkpoint file"; return EKPNP_ERR_INVALID; }
+  rc = io_ckpt_check_header(S(T, 0), h, 0, S(T, 0).p.nz);
+  if (rc) T.err = S(T, 0).err;
+  if (rc == EKPNP_OK && h.with_ghosts) { T.err = "this is a slab's per-rank checkpoint, not a whole-lattice one"; rc = EKPNP_ERR_INVALID; }
+  for (int id = 0; rc == EKPNP_OK && id < EKPNP_NFIELDS; ++id)
+    for (int i = 0; rc == EKPNP_OK && i < n; ++i)
+      if ((rc = use(T, i)) == EKPNP_OK && (rc = io_ckpt_fields(S(T, i), f, id, 1))) T.err = S(T, i).err;
+  for (int l = 0; rc == EKPNP_OK && l < S(T, 0).p.n_lattices; ++l)
+    for (int i = 0; rc == EKPNP_OK && i < n; ++i)
+      if ((rc = use(T, i)) == EKPNP_OK && (rc = io_ckpt_populations(S(T, i), f, l, 0, 1))) T.err = S(T, i).err;
+  std::fclose(f);
+  if (rc) return rc;
+  // ghost planes: what the halo exchange of the interrupted run had left there - the neighbouring
+  // slab's edge plane (only its 9 z-crossing directions are ever read), ring-closed (LBM.cu:1972,1975)
+  for (int i = 0; i < n; ++i) {
+    Ctx& c = S(T, i);
+    io_ckpt_finish_load(c, h);
+    Ctx &below = S(T, (i + n - 1) % n), &above = S(T, (i + 1) % n);
+    if ((rc = use(T, i))) return rc;
+    for (int l = 0; l < c.p.n_lattices; ++l) {
+      const size_t bytes = c.pplane * sizeof(double);
+      THIP(T, xcopy(c.cur_base(l), c.device, below.cur_base(l) + (size_t)below.nzl * below.pplane, below.device, bytes, c.stream));
+      THIP(T, xcopy(c.cur_base(l) + (size_t)(c.nzl + 1) * c.pplane, c.device, above.cur_base(l) + above.pplane, above.device, bytes, c.stream));
+    }
+  }
+  if ((rc = team_synchronize(T))) return rc;
+  if (time) *time = h.time;
+  return EKPNP_OK;
+}

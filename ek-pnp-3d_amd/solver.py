@@ -112,6 +112,7 @@ def load_library():
         "ekpnp_kernel_timing_get": (i32, [ctx, C.POINTER(i32), pd, C.POINTER(C.c_int64)]),
         "ekpnp_device_bytes": (sz, [ctx]),
         "ekpnp_graph_state": (i32, [ctx]),
+        "ekpnp_debug_sync_enabled": (i32, []),
         "ekpnp_copy_bandwidth": (i32, [ctx, sz, pd]),
         "ekpnp_halo_buffer": (i32, [ctx, i32, C.POINTER(C.c_void_p), C.POINTER(sz)]),
         "ekpnp_halo_pack": (i32, [ctx]),
@@ -138,6 +139,10 @@ def load_library():
         "ekpnp_read_data": (i32, [ctx, C.c_char_p, pd]),
         "ekpnp_save_state": (i32, [ctx, C.c_char_p, dbl]),
         "ekpnp_read_state": (i32, [ctx, C.c_char_p, pd]),
+        "ekpnp_save_checkpoint": (i32, [ctx, C.c_char_p]),
+        "ekpnp_load_checkpoint": (i32, [ctx, C.c_char_p, pd]),
+        "ekpnp_group_save_checkpoint": (i32, [ctx, C.c_char_p]),
+        "ekpnp_group_load_checkpoint": (i32, [ctx, C.c_char_p, pd]),
         "ekpnp_compute_parameters": (i32, [C.POINTER(Params), pd, pd, pd, pd, pd]),
         "ekpnp_save_scalar": (i32, [ctx, C.c_char_p, i32, C.c_uint, C.c_uint]),
         # the library's own halo transport (RCCL / peer copies)
@@ -378,6 +383,15 @@ class Solver:
             raise ValueError("unique id must be 128 bytes")
         self._ck(self._L.ekpnp_slab_attach_comm(self._h, C.c_char_p(unique_id)))
 
+    def save_checkpoint(self, path: str):
+        """fields + post-collision populations: load_checkpoint continues the run bit for bit"""
+        self._ck(self._L.ekpnp_save_checkpoint(self._h, os.fsencode(path)))
+
+    def load_checkpoint(self, path: str) -> float:
+        t = C.c_double()
+        self._ck(self._L.ekpnp_load_checkpoint(self._h, os.fsencode(path), C.byref(t)))
+        return t.value
+
     # -- z-slab pieces (driven by slab.py) ---------------------------------------------------
     def call(self, name: str):
         """Invoke a parameterless `int ekpnp_<name>(ctx)` entry point."""
@@ -534,4 +548,12 @@ class Group:
     def read_state(self, path: str) -> float:
         t = C.c_double()
         self._ck(self._L.ekpnp_group_read_state(self._g, os.fsencode(path), C.byref(t)))
+        return t.value
+
+    def save_checkpoint(self, path: str):
+        self._ck(self._L.ekpnp_group_save_checkpoint(self._g, os.fsencode(path)))
+
+    def load_checkpoint(self, path: str) -> float:
+        t = C.c_double()
+        self._ck(self._L.ekpnp_group_load_checkpoint(self._g, os.fsencode(path), C.byref(t)))
         return t.value

@@ -192,9 +192,22 @@ int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time);
  * by their extrapolation, LBM.cu:2596-2611): the 11 macroscopic fields of the owned planes as
  * raw little-endian FP64 behind a 40-byte header {"EKPNPST1", nx, ny, nz, z0, nz_local, 11,
  * time}.  Restart is the reference's: ekpnp_read_state, then ekpnp_init_equilibrium
- * (main.cu:161-175).  Slab contexts write / read their own planes (one file per rank). */
+ * (main.cu:161-175).  "Lossless" is about the FIELDS: like the reference's restart, this one
+ * re-equilibrates the populations from them, i.e. the non-equilibrium part of all four lattices
+ * is dropped and a restarted run is NOT the bitwise continuation of the interrupted one (it
+ * rejoins it as the relaxation forgets the kick: tests/test_io_gpu.py documents the size).
+ * Slab contexts write / read their own planes (one file per rank). */
 int ekpnp_save_state(ekpnp_ctx* ctx, const char* path, double time);
 int ekpnp_read_state(ekpnp_ctx* ctx, const char* path, double* time);
+
+/* Full checkpoint (no reference counterpart; the reference can only restart from fields): the 11
+ * fields AND the post-collision populations of every lattice, raw FP64 behind a 64-byte header
+ * "EKPNPCK1".  Loading it continues the interrupted run bit for bit, in a two-buffer or an in-place
+ * context alike (512^3 x 4 lattices: 128 GB).  A single context writes / reads a whole-lattice file,
+ * interchangeable with ekpnp_group_save_checkpoint / _load_checkpoint; a slab context on its own
+ * writes / reads a per-rank file that includes its two ghost planes. */
+int ekpnp_save_checkpoint(ekpnp_ctx* ctx, const char* path);
+int ekpnp_load_checkpoint(ekpnp_ctx* ctx, const char* path, double* time);
 
 /* void compute_parameters(double* T, double* M, double* C, double* Fe, double* Pr) — LBM.h:171,
  * LBM.cu:2419-2446: the dimensionless groups main.cu:38 computes for its banner.  Pure host
@@ -216,6 +229,11 @@ size_t ekpnp_device_bytes(const ekpnp_ctx* ctx);
  * copy of `bytes` bytes on the context's stream: the secondary denominator SURVEY.md 8(d) asks
  * for next to the 8 TB/s spec figure.  Allocates and frees 2 x `bytes` of scratch. */
 int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
+/* Every kernel launch of the library is checked: a rejected launch makes the entry point return
+ * EKPNP_ERR_HIP with the KERNEL's name in ekpnp_last_error.  With EKPNP_DEBUG_SYNC set in the
+ * environment the stream is additionally synchronised after every launch, so a fault inside a
+ * kernel is reported against that kernel too (debug runs; this returns 1 then). */
+int ekpnp_debug_sync_enabled(void);
 /* 1: ekpnp_step holds an instantiated 2-step hipGraph, 0: none yet, -1: capture failed (eager). */
 int ekpnp_graph_state(const ekpnp_ctx* ctx);
 
@@ -312,6 +330,8 @@ int ekpnp_group_read_data(ekpnp_group* g, const char* path, double* time);      
 /* one EKPNPST1 file for the whole lattice: interchangeable with a single context's ekpnp_save_state */
 int ekpnp_group_save_state(ekpnp_group* g, const char* path, double time);
 int ekpnp_group_read_state(ekpnp_group* g, const char* path, double* time);
+int ekpnp_group_save_checkpoint(ekpnp_group* g, const char* path);
+int ekpnp_group_load_checkpoint(ekpnp_group* g, const char* path, double* time);
 
 #ifdef __cplusplus
 }

@@ -310,3 +310,44 @@ def test_cfg5_per_rank_slab_1024x1024x128_through_the_transport(pkg):
     finally:
         s.close()
     _same_profiles(big, small)
+
+
+def test_group_checkpoint_continues_and_is_interchangeable_with_one_context(pkg, O, tmp_path):
+    shape = (24, 6, 48)
+    po = O.default_params(*shape)
+    po.pb_iterations = 8
+    p = pkg.default_params(*shape)
+    p.pb_iterations = 8
+    ck = str(tmp_path / "g.ck")
+    with pkg.Group(p, 4, devices=[0] * 4) as g:
+        g.initialization()
+        g.set_fields(O.perturb_fields(po, g.fields()))
+        g.fast_Poisson(); g.init_equilibrium(); g.step(5)
+        g.save_checkpoint(ck)
+        g.step(4)
+        want = g.fields()
+    with pkg.Group(p, 4, devices=[0] * 4) as g:   # same decomposition: bit for bit
+        assert abs(g.load_checkpoint(ck) - 5 * p.dt) < 1e-22
+        g.step(4)
+        got = g.fields()
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    others = []
+    with pkg.Group(p, 2, devices=[0] * 2) as g:   # another decomposition, and one context:
+        g.load_checkpoint(ck); g.step(4)           # same run up to the association of the z solve
+        others.append(g.fields())
+    with pkg.Solver(p) as s:
+        s.load_checkpoint(ck); s.step(4)
+        others.append(s.fields())
+        s.save_checkpoint(str(tmp_path / "s.ck"))
+    for f in others:
+        err = O.rel_l2(f, want)
+        assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err
+    with pkg.Group(p, 3, devices=[0] * 3) as g:   # a single context's file into a group
+        g.load_checkpoint(str(tmp_path / "s.ck")); g.step(2)
+        a = g.fields()
+    with pkg.Solver(p) as s:
+        s.load_checkpoint(str(tmp_path / "s.ck")); s.step(2)
+        b = s.fields()
+    err = O.rel_l2(a, b)
+    assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err

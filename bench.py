@@ -414,10 +414,38 @@ def main():
     agree(err)
     if native:
         # ONE rank makes the RCCL id, the control plane hands it round, every rank attaches (collective)
-        ident = [pkg.comm_unique_id() if rank == 0 else None]
+        err = None
+        try:
+            ident = [pkg.comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            ident, err = [None], e
         if dist is not None:
             dist.broadcast_object_list(ident, src=0)
-        sol.attach_comm(ident[0])
+        if ident[0] is not None:
+            try:
+                sol.attach_comm(ident[0])
+            except Exception as e:  # noqa: BLE001
+                err = e
+        failed = err is not None
+        if dist is not None:
+            flag = torch.tensor([1 if failed else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = bool(int(flag.item()))
+        if failed and dist is None:
+            raise SystemExit(f"bench.py: the library's RCCL transport could not be set up: {err}")
+        if failed:
+            # Safety net for a node where the in-library communicator cannot be made: the same slab
+            # contexts, halos moved by torch.distributed's own RCCL process group (slab.py) - the
+            # JSON line says which transport ran.  Every rank takes this branch together.
+            print(f"rank {rank}: ekpnp_slab_attach_comm failed ({err}); falling back to the torch.distributed RCCL transport", file=sys.stderr)
+            from ek_pnp_3d_amd.slab import DistributedSlab  # noqa: WPS433
+
+            sol.close()
+            data_group = dist.new_group(backend="nccl")
+            runner = DistributedSlab(p, rank, world, dist, group=data_group)
+            sol = runner.solver
+            native = False
+            transport = "torch.distributed RCCL process group (fallback: in-library communicator failed)"
 
     if prof is not None:
         product_pb_state(sol, p, prof)

@@ -298,15 +298,20 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
     if ((rc = dev_alloc(c, (void**)&c.edge_local, 4 * nmodes * sizeof(double)))) return bail(rc);
     if ((rc = dev_alloc(c, (void**)&c.edge_all, (size_t)nranks * 4 * nmodes * sizeof(double)))) return bail(rc);
   }
-  // batched 2-D real transforms over the owned planes (replaces cufftPlan3d, main.cu:112)
+  // batched 2-D real transforms over the owned INTERIOR planes (replaces cufftPlan3d, main.cu:112): the
+  // plates carry no unknown (poisson.cu:116-119,136-139), so their rows are neither transformed nor
+  // solved; the inverse transform writes phi itself (the z solve folds the 1/(NX NY) in) straight
+  // into the phi array
+  c.fft_z0 = (c.z0 == 0) ? 1 : 0;
+  c.fft_nz = c.nzl - c.fft_z0 - ((c.z0 + c.nzl == p->nz) ? 1 : 0);
   {
     int n[2] = {p->ny, p->nx};
     int rembed[2] = {p->ny, p->nx};      // real planes, dense
     int cembed[2] = {p->ny, c.nxh};      // half spectrum with the padded row pitch
-    hipfftResult r = hipfftPlanMany(&c.plan_fwd, 2, n, rembed, 1, p->ny * p->nx, cembed, 1, p->ny * c.nxh, HIPFFT_D2Z, c.nzl);
+    hipfftResult r = hipfftPlanMany(&c.plan_fwd, 2, n, rembed, 1, p->ny * p->nx, cembed, 1, p->ny * c.nxh, HIPFFT_D2Z, c.fft_nz);
     if (r != HIPFFT_SUCCESS) { c.plan_fwd = 0; c.err = "hipfftPlanMany (D2Z) failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
     c.have_fwd = true;
-    r = hipfftPlanMany(&c.plan_inv, 2, n, cembed, 1, p->ny * c.nxh, rembed, 1, p->ny * p->nx, HIPFFT_Z2D, c.nzl);
+    r = hipfftPlanMany(&c.plan_inv, 2, n, cembed, 1, p->ny * c.nxh, rembed, 1, p->ny * p->nx, HIPFFT_Z2D, c.fft_nz);
     if (r != HIPFFT_SUCCESS) { c.plan_inv = 0; c.err = "hipfftPlanMany (Z2D) failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
     c.have_inv = true;
     c.plans = true;
@@ -489,10 +494,10 @@ extern "C" int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per
 
 static int poisson_single(Ctx& c) {
   if (!c.rhs_ready) launch_poisson_rhs(c);
-  c.rhs_ready = false;  // the inverse transform overwrites work[]
-  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.work, (hipfftDoubleComplex*)c.spec));
+  c.rhs_ready = false;
+  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec()));
   launch_tridiag(c);
-  FFTCHK(c, hipfftExecZ2D(c.plan_inv, (hipfftDoubleComplex*)c.spec, c.work));
+  FFTCHK(c, hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out()));
   launch_phi_efield(c);
   LAUNCHCHK(c);
   return EKPNP_OK;
@@ -930,7 +935,7 @@ extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
   distrust_bound_rhs(c);
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
-  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.work, (hipfftDoubleComplex*)c.spec));
+  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec()));
   launch_slab_thomas_local(c);
   LAUNCHCHK(c);
   return EKPNP_OK;
@@ -949,7 +954,7 @@ extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   launch_slab_reduce_correct(c);
-  FFTCHK(c, hipfftExecZ2D(c.plan_inv, (hipfftDoubleComplex*)c.spec, c.work));
+  FFTCHK(c, hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out()));
   LAUNCHCHK(c);
   return EKPNP_OK;
 }

@@ -176,6 +176,12 @@ struct Ctx {
   size_t fld_bytes[EKPNP_NFIELDS] = {}; // size of that allocation (skew pad included)
   double* work = nullptr;
   double2* spec = nullptr;
+  // the transforms run over the owned interior planes [fft_z0, fft_z0 + fft_nz): right-hand side in
+  // work[], half spectrum in spec[], phi out into the phi array
+  int fft_z0 = 0, fft_nz = 0;
+  double* fft_in() const { return work + (size_t)fft_z0 * plane; }
+  hipfftDoubleComplex* fft_spec() const { return (hipfftDoubleComplex*)(spec + (size_t)fft_z0 * p.ny * nxh); }
+  double* fft_out() const { return fld[EKPNP_PHI] + (size_t)fft_z0 * plane; }
   double* cprime = nullptr;
   double* halo[4] = {};        // send-down, send-up, recv-from-below, recv-from-above
   size_t halo_doubles = 0;

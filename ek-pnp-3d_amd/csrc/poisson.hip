@@ -93,6 +93,8 @@ __global__ void __launch_bounds__(64) k_tridiag(PArgs a) {
     }
   }
   // phi[n-2] = d'[n-2]; phi[z] = d'[z] - c'[z] phi[z+1]
+  // (requesting the next block's rows before the current block's chain of 16 divisions - software
+  // pipelining at 196 VGPRs - was measured slower: 0.82 vs 0.75 ms on 512^3, profiles/r02_tridiag_variants.log)
   double pr = 0.0, pi = 0.0;
   for (int zhi = n - 2; zhi >= 1;) {
     const int zlo = ((zhi - 1) / TRI_BS) * TRI_BS + 1;  // block zlo..zhi; row zlo-1 is a checkpoint (or the wall)
@@ -133,7 +135,9 @@ __global__ void __launch_bounds__(64) k_tridiag(PArgs a) {
           pr = d[i].x - c[i] * pr;
           pi = d[i].y - c[i] * pi;
         }
-        s[(long long)z * ms] = make_double2(pr, pi);
+        // stored with the 1/(NX NY) of the unnormalised transforms folded in (poisson.cu:196: / size):
+        // the inverse FFT then delivers phi itself, straight into the phi array
+        s[(long long)z * ms] = make_double2(pr * a.inv_nxny, pi * a.inv_nxny);
       }
     }
     zhi = zlo - 1;
@@ -181,21 +185,12 @@ __global__ void __launch_bounds__(256) k_tridiag_pcr64(PArgs a) {
     lo = al * lo_l;
     up = ga * up_u;
   }
-  if (live) *s = make_double2(rr / bd, ri / bd);
+  if (live) *s = make_double2(rr / bd * a.inv_nxny, ri / bd * a.inv_nxny);  // 1/(NX NY) folded in, as in k_tridiag
 }
 
 // odd_extract + gpu_efield + gpu_bc fused (poisson.cu:191-204, 40-69): phi = ifft/(NX NY) on
 // interior planes, wall planes pinned to voltage/voltage2; E = central differences of phi,
 // periodic in x,y; Ez of a wall plane copies the neighbouring interior plane.
-__device__ __forceinline__ double phi_at(const PArgs& a, int x, int y, int z /*global*/) {
-  if (z <= 0) return a.voltage;  // z==0 wall (z==-1 is never used for a result that survives gpu_bc)
-  if (z >= a.nz - 1) return a.voltage2;
-  const int zl = z - a.z0;
-  if (zl < 0) return a.phi_lo[(long long)y * a.nx + x];
-  if (zl >= a.nzl) return a.phi_hi[(long long)y * a.nx + x];
-  return a.work[((long long)zl * a.ny + y) * a.nx + x] * a.inv_nxny;
-}
-
 // planes marched per thread: 16 on large lattices (no measurable difference between 1 and 64
 // there, profiles/r01_sweep_phi_zchunk.log), 1 on small ones where the serial chain of a column
 // would be the whole run time of the kernel
@@ -213,44 +208,6 @@ constexpr int PHI_ZCHUNK_LARGE = 16;
 // XCD-aware placement as in k_collide_bulk: the (y, z-chunk) rows are dealt to the 8 XCDs in
 // runs of 64 consecutive y, so the y+-1 neighbour rows are found in the XCD's own L2 (with rows
 // dealt one by one every L2 fetched all three rows: 4.1 GB fetched for 1.07 GB of phi).
-struct PhiColumn {
-  const double* __restrict__ work;
-  const double* __restrict__ lo;
-  const double* __restrict__ hi;
-  const double* __restrict__ vwall;  // {voltage, voltage, voltage2, voltage2} in device memory: the wall case is a pointer select too
-  long long plane, oc;
-  int z0, nzl, nz;
-  double inv;
-  // phi(x, y, z) for z0-1 <= z <= z0+nzl (phi_at() without branches: one unconditional load)
-  __device__ __forceinline__ double center(int z) const {
-    const int zl = z - z0;
-    const bool wall_lo = z <= 0, wall_hi = z >= nz - 1;
-    const bool own = !wall_lo && !wall_hi && zl >= 0 && zl < nzl;
-    const int zc = zl < 0 ? 0 : (zl >= nzl ? nzl - 1 : zl);
-    const double* p = work + (long long)zc * plane + oc;
-    p = zl < 0 ? lo + oc : p;
-    p = zl >= nzl ? hi + oc : p;
-    p = wall_lo ? vwall : p;
-    p = wall_hi ? vwall + 2 : p;
-    return *p * (own ? inv : 1.0);
-  }
-  // the same for the node pair (x, x+1), x even: one 16-byte load
-  __device__ __forceinline__ double2 center2(int z) const {
-    const int zl = z - z0;
-    const bool wall_lo = z <= 0, wall_hi = z >= nz - 1;
-    const bool own = !wall_lo && !wall_hi && zl >= 0 && zl < nzl;
-    const int zc = zl < 0 ? 0 : (zl >= nzl ? nzl - 1 : zl);
-    const double* p = work + (long long)zc * plane + oc;
-    p = zl < 0 ? lo + oc : p;
-    p = zl >= nzl ? hi + oc : p;
-    p = wall_lo ? vwall : p;
-    p = wall_hi ? vwall + 2 : p;
-    const double2 v = *reinterpret_cast<const double2*>(p);
-    const double sc = own ? inv : 1.0;
-    return make_double2(v.x * sc, v.y * sc);
-  }
-};
-
 // 16-byte store to an address that is only guaranteed to be 8-byte aligned (caller-bound field
 // arrays, ekpnp_bind_field): global_store_dwordx4 needs dword alignment only
 typedef double pair8 __attribute__((ext_vector_type(2), aligned(8)));
@@ -258,6 +215,46 @@ __device__ __forceinline__ void store_pair(double* p, double a, double b) {
   pair8 v = {a, b};
   *reinterpret_cast<pair8*>(p) = v;
 }
+__device__ __forceinline__ double2 load_pair(const double* p) {
+  const pair8 v = *reinterpret_cast<const pair8*>(p);
+  return make_double2(v.x, v.y);
+}
+
+struct PhiColumn {
+  const double* __restrict__ work;   // the phi array: its interior planes were written by the inverse transform
+  const double* __restrict__ lo;
+  const double* __restrict__ hi;
+  const double* __restrict__ vwall;  // {voltage, voltage, voltage2, voltage2} in device memory: the wall case is a pointer select too
+  long long plane, oc;
+  int z0, nzl, nz;
+  // phi(x, y, z) for z0-1 <= z <= z0+nzl (phi_at() without branches: one unconditional load)
+  __device__ __forceinline__ double center(int z) const {
+    const int zl = z - z0;
+    const bool wall_lo = z <= 0, wall_hi = z >= nz - 1;
+    const int zc = zl < 0 ? 0 : (zl >= nzl ? nzl - 1 : zl);
+    const double* p = work + (long long)zc * plane + oc;
+    p = zl < 0 ? lo + oc : p;
+    p = zl >= nzl ? hi + oc : p;
+    p = wall_lo ? vwall : p;
+    p = wall_hi ? vwall + 2 : p;
+    return *p;
+  }
+  // the same for the node pair (x, x+1), x even: one 16-byte load
+  __device__ __forceinline__ double2 center2(int z) const {
+    const int zl = z - z0;
+    const bool wall_lo = z <= 0, wall_hi = z >= nz - 1;
+    const int zc = zl < 0 ? 0 : (zl >= nzl ? nzl - 1 : zl);
+    const double* p = work + (long long)zc * plane + oc;
+    p = zl < 0 ? lo + oc : p;
+    p = zl >= nzl ? hi + oc : p;
+    p = wall_lo ? vwall : p;
+    p = wall_hi ? vwall + 2 : p;
+    const pair8 v = *reinterpret_cast<const pair8*>(p);  // a caller-bound phi array may be 8-byte aligned only
+    return make_double2(v.x, v.y);
+  }
+};
+
+
 
 template <int PHI_ZCHUNK>
 __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, const int nrows) {
@@ -277,9 +274,9 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
   const long long oc = (long long)y * a.nx + x;
   const long long oxm = (long long)y * a.nx + xm1, oxp = (long long)y * a.nx + xp1;
   const long long oym = (long long)ym1 * a.nx + x, oyp = (long long)yp1 * a.nx + x;
-  const PhiColumn col{a.work, a.phi_lo, a.phi_hi, a.vwall, a.plane, oc, a.z0, a.nzl, a.nz, a.inv_nxny};
-  const double* __restrict__ w = a.work;
-  double* __restrict__ o_phi = a.fld[EKPNP_PHI];
+  const PhiColumn col{a.fld[EKPNP_PHI], a.phi_lo, a.phi_hi, a.vwall, a.plane, oc, a.z0, a.nzl, a.nz};
+  const double* w = a.fld[EKPNP_PHI];  // interior planes: phi as the inverse transform left it (wall planes: written below)
+  double* o_phi = a.fld[EKPNP_PHI];
   double* __restrict__ o_ex = a.fld[EKPNP_EX];
   double* __restrict__ o_ey = a.fld[EKPNP_EY];
   double* __restrict__ o_ez = a.fld[EKPNP_EZ];
@@ -301,12 +298,12 @@ __global__ void __launch_bounds__(256) k_phi_efield(PArgs a, const int nxb, cons
 
     const bool wall = z == 0 || z == a.nz - 1;
     const double vw = z == 0 ? a.voltage : a.voltage2;
-    const double exm = wall ? vw : nxm * a.inv_nxny, exp_ = wall ? vw : nxp * a.inv_nxny;
-    const double eym = wall ? vw : nym * a.inv_nxny, eyp = wall ? vw : nyp * a.inv_nxny;
+    const double exm = wall ? vw : nxm, exp_ = wall ? vw : nxp;
+    const double eym = wall ? vw : nym, eyp = wall ? vw : nyp;
     const long long i = (long long)zl * a.plane + oc;
     // (plain stores: non-temporal ones, other chunk lengths and block widths measured the same,
     // profiles/r01_sweep_phi_variants.log)
-    o_phi[i] = p0;
+    if (wall) o_phi[i] = p0;  // odd_extract pins the plates (poisson.cu:198-203); the interior is already there
     // the reference's expression 0.5*(a - b)/d (poisson.cu:53-55), kept so that E is the same
     // bits as a central difference of the returned phi
     o_ex[i] = 0.5 * (exm - exp_) / a.dx;
@@ -350,9 +347,9 @@ __global__ void __launch_bounds__(256) k_phi_efield_x2(PArgs a, const int nxb, c
   const bool edge = lane == 0 || lane == 63;
   const int xe = lane == 0 ? (x0 == 0 ? a.nx - 1 : x0 - 1) : (x0 + 2 == a.nx ? 0 : x0 + 2);
   const long long oe = (long long)y * a.nx + xe;
-  const PhiColumn col{a.work, a.phi_lo, a.phi_hi, a.vwall, a.plane, oc, a.z0, a.nzl, a.nz, a.inv_nxny};
-  const double* __restrict__ w = a.work;
-  double* __restrict__ o_phi = a.fld[EKPNP_PHI];
+  const PhiColumn col{a.fld[EKPNP_PHI], a.phi_lo, a.phi_hi, a.vwall, a.plane, oc, a.z0, a.nzl, a.nz};
+  const double* w = a.fld[EKPNP_PHI];  // interior planes: phi as the inverse transform left it (wall planes: written below)
+  double* o_phi = a.fld[EKPNP_PHI];
   double* __restrict__ o_ex = a.fld[EKPNP_EX];
   double* __restrict__ o_ey = a.fld[EKPNP_EY];
   double* __restrict__ o_ez = a.fld[EKPNP_EZ];
@@ -360,7 +357,7 @@ __global__ void __launch_bounds__(256) k_phi_efield_x2(PArgs a, const int nxb, c
   double2 pm = col.center2(a.z0 + zl0 - 1);
   double2 p0 = col.center2(a.z0 + zl0);
   const double* wz = w + (long long)zl0 * a.plane;
-  double2 nym = *reinterpret_cast<const double2*>(wz + oym), nyp = *reinterpret_cast<const double2*>(wz + oyp);
+  double2 nym = load_pair(wz + oym), nyp = load_pair(wz + oyp);
   double ne = edge ? wz[oe] : 0.0;
   double2 pp = col.center2(a.z0 + zl0 + 1);
 // (no unroll request: the lane exchange is a convergent operation, the optimizer declines)
@@ -369,20 +366,20 @@ __global__ void __launch_bounds__(256) k_phi_efield_x2(PArgs a, const int nxb, c
     // next plane's operands first (clamped to the chunk: the last iteration re-reads its own plane)
     const int zn = zl + 1 < zl1 ? zl + 1 : zl;
     const double* wn = w + (long long)zn * a.plane;
-    const double2 n_ym = *reinterpret_cast<const double2*>(wn + oym), n_yp = *reinterpret_cast<const double2*>(wn + oyp);
+    const double2 n_ym = load_pair(wn + oym), n_yp = load_pair(wn + oyp);
     const double n_e = edge ? wn[oe] : 0.0;
     const double2 n_pp = col.center2(a.z0 + zn + 1);
 
     const bool wall = z == 0 || z == a.nz - 1;
     const double vw = z == 0 ? a.voltage : a.voltage2;
-    const double es = wall ? vw : ne * a.inv_nxny;
+    const double es = wall ? vw : ne;
     const double from_left = __shfl_up(p0.y, 1, 64), from_right = __shfl_down(p0.x, 1, 64);
     const double left = lane == 0 ? es : from_left;     // phi(x0 - 1)
     const double right = lane == 63 ? es : from_right;  // phi(x0 + 2)
-    const double eym0 = wall ? vw : nym.x * a.inv_nxny, eym1 = wall ? vw : nym.y * a.inv_nxny;
-    const double eyp0 = wall ? vw : nyp.x * a.inv_nxny, eyp1 = wall ? vw : nyp.y * a.inv_nxny;
+    const double eym0 = wall ? vw : nym.x, eym1 = wall ? vw : nym.y;
+    const double eyp0 = wall ? vw : nyp.x, eyp1 = wall ? vw : nyp.y;
     const long long i = (long long)zl * a.plane + oc;
-    store_pair(o_phi + i, p0.x, p0.y);
+    if (wall) store_pair(o_phi + i, p0.x, p0.y);  // the plates; the interior is already there
     // the reference's expression 0.5*(a - b)/d (poisson.cu:53-55)
     store_pair(o_ex + i, 0.5 * (left - p0.y) / a.dx, 0.5 * (p0.x - right) / a.dx);
     store_pair(o_ey + i, 0.5 * (eym0 - eyp0) / a.dy, 0.5 * (eym1 - eyp1) / a.dy);
@@ -579,7 +576,7 @@ __global__ void k_slab_reduce_correct(PArgs a, int rank, int nranks, int row_a, 
           xr = (d[i].x - glr * wv[i]) - c[i] * xr;
           xi = (d[i].y - gli * wv[i]) - c[i] * xi;
         }
-        s[(long long)(k - 1) * ms] = make_double2(xr, xi);
+        s[(long long)(k - 1) * ms] = make_double2(xr * a.inv_nxny, xi * a.inv_nxny);  // 1/(NX NY) folded in, as in k_tridiag
       }
     }
     khi = klo - 1;
@@ -591,8 +588,9 @@ __global__ void k_phi_halo_pack(PArgs a, double* __restrict__ send_dn, double* _
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.plane) return;
   const int zb = a.z0, zt = a.z0 + a.nzl - 1;
-  send_dn[i] = zb == 0 ? a.voltage : a.work[i] * a.inv_nxny;
-  send_up[i] = zt == a.nz - 1 ? a.voltage2 : a.work[(long long)(a.nzl - 1) * a.plane + i] * a.inv_nxny;
+  const double* phi = a.fld[EKPNP_PHI];  // interior planes hold the solution already (the plates may not yet)
+  send_dn[i] = zb == 0 ? a.voltage : phi[i];
+  send_up[i] = zt == a.nz - 1 ? a.voltage2 : phi[(long long)(a.nzl - 1) * a.plane + i];
 }
 
 int build_cprime(Ctx& c) {

@@ -55,11 +55,12 @@ def device_tensor(ptr: int, n: int):
 class RingTransport:
     """Neighbour ring + all-gather over a torch.distributed process group."""
 
-    def __init__(self, dist, rank: int, world: int):
+    def __init__(self, dist, rank: int, world: int, group=None):
         self.dist, self.rank, self.world = dist, rank, world
+        self.group = group  # None: the default process group
         self.up = (rank + 1) % world
         self.down = (rank - 1) % world
-        self.backend = dist.get_backend()
+        self.backend = dist.get_backend(group)
         self.host_staged = self.backend != "nccl"
 
     # -- ring -------------------------------------------------------------------------------
@@ -72,11 +73,12 @@ class RingTransport:
             bufs = [send_up.cpu(), send_dn.cpu(), recv_lo.cpu(), recv_hi.cpu()]
         else:
             bufs = [send_up, send_dn, recv_lo, recv_hi]
+        g = self.group
         ops = [
-            dist.P2POp(dist.isend, bufs[0], self.up),
-            dist.P2POp(dist.isend, bufs[1], self.down),
-            dist.P2POp(dist.irecv, bufs[2], self.down),
-            dist.P2POp(dist.irecv, bufs[3], self.up),
+            dist.P2POp(dist.isend, bufs[0], self.up, group=g),
+            dist.P2POp(dist.isend, bufs[1], self.down, group=g),
+            dist.P2POp(dist.irecv, bufs[2], self.down, group=g),
+            dist.P2POp(dist.irecv, bufs[3], self.up, group=g),
         ]
         return dist.batch_isend_irecv(ops), bufs, (recv_lo, recv_hi)
 
@@ -97,12 +99,12 @@ class RingTransport:
         if self.host_staged:
             src = local.cpu()
             parts = [src.new_empty(src.shape) for _ in range(self.world)]
-            dist.all_gather(parts, src)
+            dist.all_gather(parts, src, group=self.group)
             n = src.numel()
             for r, p in enumerate(parts):
                 gathered[r * n : (r + 1) * n].copy_(p)
         else:
-            dist.all_gather_into_tensor(gathered, local)
+            dist.all_gather_into_tensor(gathered, local, group=self.group)
 
 
 class _SlabBuffers:
@@ -118,7 +120,7 @@ class _SlabBuffers:
 class DistributedSlab:
     """One rank of a z-slab run.  Mirrors Solver's reference-named methods."""
 
-    def __init__(self, params: Params, rank: int, world: int, dist):
+    def __init__(self, params: Params, rank: int, world: int, dist, group=None):
         import torch
 
         self.torch = torch
@@ -128,7 +130,7 @@ class DistributedSlab:
         self.stream = torch.cuda.Stream()
         self.solver.set_stream(self.stream.cuda_stream)
         self.buf = _SlabBuffers(self.solver)
-        self.tr = RingTransport(dist, rank, world)
+        self.tr = RingTransport(dist, rank, world, group)
 
     def close(self):
         self.solver.close()
@@ -186,7 +188,7 @@ class DistributedSlab:
     # -- diagnostics (main.cu:211-222): every slab reduces its own planes, the ranks combine ----
     def _allreduce(self, value: float, op):
         t = self.torch.tensor([value], dtype=self.torch.float64, device="cpu" if self.tr.host_staged else "cuda")
-        self.tr.dist.all_reduce(t, op=op)
+        self.tr.dist.all_reduce(t, op=op, group=self.tr.group)
         return float(t.item())
 
     def current(self) -> float:

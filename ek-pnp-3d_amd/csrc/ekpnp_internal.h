@@ -52,7 +52,10 @@ __host__ __device__ constexpr int dn_dir(int k) {
 // lie gigabytes apart (pure-copy ceiling of the two shapes on one box: 5.95 vs 5.48 TB/s,
 // profiles/r01_stream_probe_aosoa.log).  Lanes of the last tile beyond nx are never touched.
 constexpr int TILE = Q * 64;
-constexpr int TRI_CHECK = 16;  // the single-context z solve keeps every 16th row of c' and of d' (poisson.hip TRI_BS)
+#ifndef EKPNP_TRI_CHECK
+#define EKPNP_TRI_CHECK 16  // tuning knob (8 / 32 measured: profiles/r02_tridiag_variants.log)
+#endif
+constexpr int TRI_CHECK = EKPNP_TRI_CHECK;  // the z solves keep every TRI_CHECK-th row of c' and of d' (poisson.hip TRI_BS)
 __host__ __device__ inline long long pop_xoff(int x) { return (long long)(x >> 6) * TILE + (x & 63); }
 
 // Everything a kernel needs, passed by value.

@@ -72,7 +72,10 @@ __global__ void k_build_cprime(double* cprime, int nx, int ny, int nz, int nxh, 
 // division per row, hidden behind the loads), the back substitution restarts it from the table row
 // below each block: 3.4 GB, i.e. the spectrum read twice and written once and nothing else.
 constexpr int TRI_BS = TRI_CHECK;
-__global__ void __launch_bounds__(64) k_tridiag(PArgs a) {
+#ifndef EKPNP_TRI_THREADS
+#define EKPNP_TRI_THREADS 64  // tuning knob: modes (threads) per workgroup of the z solve
+#endif
+__global__ void __launch_bounds__(EKPNP_TRI_THREADS) k_tridiag(PArgs a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   const long long ms = (long long)a.ny * a.nxh;
   if (m >= ms) return;
@@ -662,7 +665,7 @@ void launch_tridiag(Ctx& c) {
   if (c.p.nz - 2 <= 64)
     hipLaunchKernelGGL(k_tridiag_pcr64, dim3((nm + 3) / 4), dim3(256), 0, c.stream, a);
   else
-    hipLaunchKernelGGL(k_tridiag, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a);
+    hipLaunchKernelGGL(k_tridiag, dim3((nm + EKPNP_TRI_THREADS - 1) / EKPNP_TRI_THREADS), dim3(EKPNP_TRI_THREADS), 0, c.stream, a);
   note_launch(c, "k_tridiag");
 }
 

@@ -12,10 +12,17 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"))
 
 def agg(path):
+    """mean counter value per kernel over its LARGEST launches only (the bench also runs the same
+    kernels on a 16x16x257 replica for its start state; those launches must not dilute the mean)"""
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in d.items()}
+        d[r["Kernel_Name"]].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
+    out = {}
+    for k, v in d.items():
+        g = max(x[0] for x in v)
+        big = [x[1] for x in v if x[0] == g]
+        out[k] = sum(big) / len(big)
+    return out
 
 cf, cw = agg(os.path.join(src, "calib_fetch", "pmc_counter_collection.csv")), agg(os.path.join(src, "calib_write", "pmc_counter_collection.csv"))
 copy_name = next(k for k in cf if k.startswith("k_copy8("))

@@ -1,4 +1,9 @@
-"""z-slab decomposition of the EK-PNP step over the GPUs of one node.
+"""z-slab decomposition of the EK-PNP step over the GPUs of one node with the
+transport in PYTHON (torch.distributed).  Since round 2 the library moves the halos itself
+(csrc/slab_team.hip: ekpnp_slab_attach_comm / ekpnp_group_*, RCCL or peer copies on a comm stream);
+this module stays as the worked example of INTEGRATION.md section 5(c) - a host's own transport over
+the split entry points -, as the gloo rehearsal of the multi-process flow on a one-GPU box, and as
+bench.py's safety net when the in-library communicator cannot be made.
 
 No reference counterpart: the reference is single-GPU (`cudaSetDevice(0)`, main.cu:58).  One
 process per GPU; rank r owns planes [r*NZ/P, (r+1)*NZ/P).  x and y stay whole, so the x-y

@@ -78,6 +78,15 @@ hipError_t take_launch_error(Ctx& c) {
 }
 }  // namespace ekpnp
 
+// measurement hook (tools/sweep_zchunk.py): change a launch-shape knob of a live context
+extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
+  if (!ctx || !knob) return EKPNP_ERR_INVALID;
+  Ctx& c = ctx->c;
+  if (std::strcmp(knob, "ab_zchunk") == 0 && value >= 0) { c.ab_zchunk = value; return EKPNP_OK; }
+  c.err = "ekpnp_tune: unknown knob or bad value";
+  return EKPNP_ERR_INVALID;
+}
+
 extern "C" int ekpnp_debug_sync_enabled(void) { return std::getenv("EKPNP_DEBUG_SYNC") != nullptr; }
 
 static void drop_graph(Ctx& c) {
@@ -236,6 +245,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   }
   c.own_stream = true;
   if (hipGetDevice(&c.device) != hipSuccess) { c.err = "hipGetDevice failed"; return bail(EKPNP_ERR_HIP); }
+  if (const char* e = std::getenv("EKPNP_BULK_ZCHUNK")) c.ab_zchunk = std::atoi(e) > 0 ? std::atoi(e) : 0;
   // In-place mode: one buffer per lattice with `shift` spare planes.  A sweep writes plane z of
   // the new state `shift` planes below (parity 0, bulk launches of `zchunk` planes in ascending z)
   // or above (parity 1, descending) where plane z of the old state lies; shift >= zchunk + 1
@@ -668,7 +678,12 @@ static int collide_range(Ctx& c, int zb, int ze, bool timed) {
     int rc = timing_begin(c, &stop);
     if (rc) return rc;
   }
-  launch_collide_bulk(c, zb, ze);
+  // the two-buffer sweep in launches of c.ab_zchunk planes (0: one launch); ekpnp_tune / EKPNP_BULK_ZCHUNK
+  const int zchunk = c.ab_zchunk;
+  if (zchunk > 0)
+    for (int z = zb; z < ze; z += zchunk) launch_collide_bulk(c, z, z + zchunk < ze ? z + zchunk : ze);
+  else
+    launch_collide_bulk(c, zb, ze);
   if (stop) {
     HIPCHK(c, hipEventRecord(*stop, c.stream));
     c.timed_nodes = (long long)(ze - zb) * (long long)c.plane;

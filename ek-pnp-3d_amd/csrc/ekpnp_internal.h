@@ -161,6 +161,7 @@ struct Ctx {
   bool inplace = false;
   int shift = 0;               // planes the lattice moves per sweep in in-place mode (0 in A/B mode)
   int zchunk = 0;              // planes per bulk launch in in-place mode (shift >= zchunk + 1)
+  int ab_zchunk = 0;           // two-buffer mode: planes per bulk launch of the sweep (0: one launch)
   // base pointer of lattice l's CURRENT state (plane zg = 0 is the ghost plane below)
   double* cur_base(int l) const {
     if (!inplace) return pop[cur][l];

@@ -113,6 +113,7 @@ def load_library():
         "ekpnp_device_bytes": (sz, [ctx]),
         "ekpnp_graph_state": (i32, [ctx]),
         "ekpnp_debug_sync_enabled": (i32, []),
+        "ekpnp_tune": (i32, [ctx, C.c_char_p, i32]),
         "ekpnp_copy_bandwidth": (i32, [ctx, sz, pd]),
         "ekpnp_halo_buffer": (i32, [ctx, i32, C.POINTER(C.c_void_p), C.POINTER(sz)]),
         "ekpnp_halo_pack": (i32, [ctx]),
@@ -371,6 +372,9 @@ class Solver:
         t = C.c_double()
         self._ck(self._L.ekpnp_read_state(self._h, os.fsencode(path), C.byref(t)))
         return t.value
+
+    def tune(self, knob: str, value: int):
+        self._ck(self._L.ekpnp_tune(self._h, knob.encode(), int(value)))
 
     def invalidate_rhs(self):
         self._ck(self._L.ekpnp_invalidate_rhs(self._h))

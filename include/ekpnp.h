@@ -229,6 +229,9 @@ size_t ekpnp_device_bytes(const ekpnp_ctx* ctx);
  * copy of `bytes` bytes on the context's stream: the secondary denominator SURVEY.md 8(d) asks
  * for next to the 8 TB/s spec figure.  Allocates and frees 2 x `bytes` of scratch. */
 int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
+/* Launch-shape knobs of a live context, for tuning sweeps (tools/sweep_zchunk.py).  "ab_zchunk":
+ * planes per launch of the two-buffer collide sweep (0 = the whole sweep in one launch). */
+int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value);
 /* Every kernel launch of the library is checked: a rejected launch makes the entry point return
  * EKPNP_ERR_HIP with the KERNEL's name in ekpnp_last_error.  With EKPNP_DEBUG_SYNC set in the
  * environment the stream is additionally synchronised after every launch, so a fault inside a

@@ -351,3 +351,26 @@ def test_group_checkpoint_continues_and_is_interchangeable_with_one_context(pkg,
         b = s.fields()
     err = O.rel_l2(a, b)
     assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err
+
+
+@pytest.mark.parametrize("nl", [3, 1])
+def test_group_with_fewer_lattices_vs_oracle(pkg, O, nl):
+    """cfg2 physics (f + h + hn, Ra = 0) and cfg1 physics (fluid only, body force) on 3 slabs."""
+    po = O.default_params(40, 6, 36)
+    po.pb_iterations = 8
+    po.Ra = 0.0
+    if nl == 1:
+        po.chargeinf, po.TH, po.exf = 0.0, 0.0, 1e9
+    po.n_lattices = nl
+    orc = O.Oracle(po)
+    orc.initialization()
+    start = O.perturb_fields(po, orc.fields()) if nl == 3 else orc.fields()
+    orc.set_fields(start); orc.fast_poisson(); orc.init_equilibrium(); orc.step(6)
+    want = orc.fields()
+    with pkg.Group(_mirror(pkg, po), 3, devices=[0] * 3) as g:
+        g.initialization()
+        g.set_fields(start); g.fast_Poisson(); g.init_equilibrium(); g.step(6)
+        got = g.fields()
+    skip = ("T",) if nl == 3 else ("T", "c", "cn", "phi", "E")
+    groups = {k: v for k, v in O.GROUPS.items() if k not in skip}
+    _check(O, got, want, groups, f"{nl} lattices")

@@ -476,9 +476,12 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __r
 //   u1_{i+1} X_i + Y_i + um_{i+1} Y_{i+1}     = p_first(i+1)
 // u1/um of slab j are those of its row count: type 0 (first/last slab, nzl-1 rows) or 1 (nzl).
 constexpr int MAXR = 16;
-__global__ void k_slab_reduce_correct(PArgs a, int rank, int nranks, int row_a, int m, const double* __restrict__ edges_all,
-                                      const double* __restrict__ u1um_edge, const double* __restrict__ u1um_mid,
-                                      const double* __restrict__ w) {
+// the interface system is tiny (2(P-1) unknowns per mode) but wants per-thread arrays; it has a
+// kernel of its own so that the sweep below keeps its registers and needs no scratch memory
+// (fused, the sweep carried 1.8 KB of scratch per lane: 0.650 ms on a 512^3 slab against 0.458 + 0.006 ms
+// split, profiles/r02_slab_after_kernel_stats.csv)
+__global__ void k_slab_interface(PArgs a, int rank, int nranks, const double* __restrict__ edges_all, const double* __restrict__ u1um_edge,
+                                 const double* __restrict__ u1um_mid, double* __restrict__ g) {
   const int md = blockIdx.x * blockDim.x + threadIdx.x;
   const long long ms = (long long)a.ny * a.nxh;
   if (md >= ms) return;
@@ -526,8 +529,18 @@ __global__ void k_slab_reduce_correct(PArgs a, int rank, int nranks, int row_a, 
     Yr[i] = (-d21[i] * bxr + d11[i] * byr) / det;
     Yi[i] = (-d21[i] * bxi + d11[i] * byi) / det;
   }
-  const double glr = rank > 0 ? Xr[rank - 1] : 0.0, gli = rank > 0 ? Xi[rank - 1] : 0.0;
-  const double ghr = rank < nranks - 1 ? Yr[rank] : 0.0, ghi = rank < nranks - 1 ? Yi[rank] : 0.0;
+  // the two values this rank's rows see: x just below its first row, x just above its last row
+  g[md] = rank > 0 ? Xr[rank - 1] : 0.0;
+  g[ms + md] = rank > 0 ? Xi[rank - 1] : 0.0;
+  g[2 * ms + md] = rank < nranks - 1 ? Yr[rank] : 0.0;
+  g[3 * ms + md] = rank < nranks - 1 ? Yi[rank] : 0.0;
+}
+
+__global__ void __launch_bounds__(64) k_slab_reduce_correct(PArgs a, int row_a, int m, const double* __restrict__ g, const double* __restrict__ w) {
+  const int md = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ms = (long long)a.ny * a.nxh;
+  if (md >= ms) return;
+  const double glr = g[md], gli = g[ms + md], ghr = g[2 * ms + md], ghi = g[3 * ms + md];
   // back substitution of A x = r - g_lo e_1 - g_hi e_m; d' is recomputed block by block from the
   // checkpoints stage 1 left in every TRI_BS-th row (as in k_tridiag)
   double2* s = a.spec + md + (long long)row_a * ms;
@@ -642,8 +655,11 @@ void launch_slab_thomas_local(Ctx& c) {
 void launch_slab_reduce_correct(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
-  hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.slab_row_a, c.slab_m,
-                     c.edge_all, c.u1um[0], c.u1um[1], c.slab_w);
+  // the edge buffer of this rank has been gathered and is free again: it takes (g_lo, g_hi)
+  hipLaunchKernelGGL(k_slab_interface, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.edge_all, c.u1um[0], c.u1um[1],
+                     c.edge_local);
+  note_launch(c, "k_slab_interface");
+  hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.edge_local, c.slab_w);
   note_launch(c, "k_slab_reduce_correct");
 }
 

@@ -72,6 +72,15 @@ __global__ void k_build_cprime(double* cprime, int nx, int ny, int nz, int nxh, 
 // division per row, hidden behind the loads), the back substitution restarts it from the table row
 // below each block: 3.4 GB, i.e. the spectrum read twice and written once and nothing else.
 constexpr int TRI_BS = TRI_CHECK;
+// The solution rows are not read again before the inverse transform has gone through all of them:
+// non-temporal stores (0.744 -> 0.723 ms on 512^3; non-temporal LOADS in the forward sweep change
+// nothing: profiles/r02_tridiag_variants.log).  EKPNP_TRI_PLAIN_STORE builds the A/B partner.
+#ifndef EKPNP_TRI_PLAIN_STORE
+#define TRI_STORE(ptr, v) do { double2 v_ = (v); __builtin_nontemporal_store(v_.x, &(ptr)->x); __builtin_nontemporal_store(v_.y, &(ptr)->y); } while (0)
+#else
+#define TRI_STORE(ptr, v) (*(ptr) = (v))
+#endif
+#define TRI_LOAD_FWD(ptr) (*(ptr))
 #ifndef EKPNP_TRI_THREADS
 #define EKPNP_TRI_THREADS 64  // tuning knob: modes (threads) per workgroup of the z solve
 #endif
@@ -88,7 +97,7 @@ __global__ void __launch_bounds__(EKPNP_TRI_THREADS) k_tridiag(PArgs a) {
     double dr = 0.0, di = 0.0, c = 0.0;
 #pragma unroll 8
     for (int z = 1; z <= n - 2; ++z) {
-      const double2 r = s[(long long)z * ms];
+      const double2 r = TRI_LOAD_FWD(s + (long long)z * ms);
       c = 1.0 / (b - c);
       dr = (dz2 * r.x - dr) * c;
       di = (dz2 * r.y - di) * c;
@@ -140,7 +149,7 @@ __global__ void __launch_bounds__(EKPNP_TRI_THREADS) k_tridiag(PArgs a) {
         }
         // stored with the 1/(NX NY) of the unnormalised transforms folded in (poisson.cu:196: / size):
         // the inverse FFT then delivers phi itself, straight into the phi array
-        s[(long long)z * ms] = make_double2(pr * a.inv_nxny, pi * a.inv_nxny);
+        TRI_STORE(s + (long long)z * ms, make_double2(pr * a.inv_nxny, pi * a.inv_nxny));
       }
     }
     zhi = zlo - 1;
@@ -197,7 +206,10 @@ __global__ void __launch_bounds__(256) k_tridiag_pcr64(PArgs a) {
 // planes marched per thread: 16 on large lattices (no measurable difference between 1 and 64
 // there, profiles/r01_sweep_phi_zchunk.log), 1 on small ones where the serial chain of a column
 // would be the whole run time of the kernel
-constexpr int PHI_ZCHUNK_LARGE = 16;
+#ifndef EKPNP_PHI_ZCHUNK
+#define EKPNP_PHI_ZCHUNK 16  // A/B knob
+#endif
+constexpr int PHI_ZCHUNK_LARGE = EKPNP_PHI_ZCHUNK;
 
 // One thread marches up a column of PHI_ZCHUNK planes with phi(z-1), phi(z), phi(z+1) in
 // registers: every phi value is read once for the three z uses (the x+-1 / y+-1 neighbours come
@@ -216,7 +228,11 @@ constexpr int PHI_ZCHUNK_LARGE = 16;
 typedef double pair8 __attribute__((ext_vector_type(2), aligned(8)));
 __device__ __forceinline__ void store_pair(double* p, double a, double b) {
   pair8 v = {a, b};
+#ifndef EKPNP_PHI_PLAIN_STORE  // E is next read by the collide of the following step, tens of ms later:
+  __builtin_nontemporal_store(v, reinterpret_cast<pair8*>(p));  // non-temporal (814 vs 823-848 us, profiles/r02_phi_variants.log)
+#else
   *reinterpret_cast<pair8*>(p) = v;
+#endif
 }
 __device__ __forceinline__ double2 load_pair(const double* p) {
   const pair8 v = *reinterpret_cast<const pair8*>(p);
@@ -592,7 +608,7 @@ __global__ void __launch_bounds__(64) k_slab_reduce_correct(PArgs a, int row_a, 
           xr = (d[i].x - glr * wv[i]) - c[i] * xr;
           xi = (d[i].y - gli * wv[i]) - c[i] * xi;
         }
-        s[(long long)(k - 1) * ms] = make_double2(xr * a.inv_nxny, xi * a.inv_nxny);  // 1/(NX NY) folded in, as in k_tridiag
+        TRI_STORE(s + (long long)(k - 1) * ms, make_double2(xr * a.inv_nxny, xi * a.inv_nxny));  // 1/(NX NY) folded in, as in k_tridiag
       }
     }
     khi = klo - 1;
@@ -693,7 +709,10 @@ void launch_phi_efield(Ctx& c) {
   const long long per_xcd = ((long long)nrows + 8 * 64 - 1) / (8 * 64) * 64;
   static const bool no_x2 = std::getenv("EKPNP_PHI_X1") != nullptr;  // A/B knob: the one-node-per-lane kernel everywhere
   if (!small && !no_x2 && c.p.nx % 128 == 0) {  // whole waves of node pairs
-    const int bx = c.p.nx >= 512 ? 256 : c.p.nx / 2;  // threads per block, each two nodes
+#ifndef EKPNP_PHI_X2_THREADS
+#define EKPNP_PHI_X2_THREADS 256  // A/B knob
+#endif
+    const int bx = c.p.nx >= 2 * EKPNP_PHI_X2_THREADS ? EKPNP_PHI_X2_THREADS : c.p.nx / 2;  // threads per block, each two nodes
     const int nxb = c.p.nx / (2 * bx);
     hipLaunchKernelGGL(k_phi_efield_x2<PHI_ZCHUNK_LARGE>, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
     note_launch(c, "k_phi_efield_x2<PHI_ZCHUNK_LARGE>");

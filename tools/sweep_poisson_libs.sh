@@ -8,5 +8,9 @@ for v in $1; do
   lib="$ROOT/ek-pnp-3d_amd/libekpnp_$v.so"; [ "$v" = base ] && lib="$ROOT/ek-pnp-3d_amd/libekpnp.so"
   out="/tmp/sweep_$v"; rm -rf "$out"
   EKPNP_LIBRARY=$lib timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o t -- python3 "$ROOT/tools/time_poisson.py" "$GRID" > "$out.log" 2>&1
-  echo "variant=$v: $(grep -h 'k_tridiag\|k_phi_efield' $out/t_kernel_stats.csv | awk -F, '{printf "%s avg %.1f us; ", substr($1,1,40), $4/1000}')"
+  python3 - "$v" "$out/t_kernel_stats.csv" <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[2])) if "k_tridiag" in r["Name"] or "k_phi_efield" in r["Name"]]
+print("variant=%s: " % sys.argv[1] + "; ".join("%s avg %.1f us" % (r["Name"].split("(")[0].replace("void ", ""), float(r["AverageNs"]) / 1e3) for r in rows))
+PY
 done

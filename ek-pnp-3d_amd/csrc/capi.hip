@@ -203,7 +203,6 @@ static int validate(const ekpnp_params* p, int rank, int nranks, std::string& er
   if (p->n_lattices < 4 && p->Ra != 0.0) { err = "n_lattices < 4 requires Ra == 0 (temperature feeds the buoyancy force, LBM.cu:637)"; return EKPNP_ERR_INVALID; }
   if (p->n_lattices == 1 && p->chargeinf != 0.0) { err = "n_lattices == 1 requires chargeinf == 0"; return EKPNP_ERR_INVALID; }
   if (nranks < 1 || rank < 0 || rank >= nranks) { err = "bad rank/nranks"; return EKPNP_ERR_INVALID; }
-  if (p->nz % nranks != 0) { err = "nz must be divisible by nranks"; return EKPNP_ERR_INVALID; }
   if (nranks > 1 && p->nz / nranks < 4) { err = "each z slab needs at least 4 planes"; return EKPNP_ERR_INVALID; }
   if (!(p->dx > 0 && p->dy > 0 && p->dz > 0 && p->dt > 0 && p->CFL > 0 && p->cs_square > 0 && p->Lx > 0 && p->Ly > 0 && p->Lz > 0)) {
     err = "dx, dy, dz, dt, CFL, cs_square, Lx, Ly, Lz must be positive"; return EKPNP_ERR_INVALID;
@@ -224,8 +223,8 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.p = *p;
   c.rank = rank; c.nranks = nranks;
   c.slab = slab;
-  c.nzl = p->nz / nranks;
-  c.z0 = rank * c.nzl;
+  c.z0 = slab_begin(p->nz, nranks, rank);
+  c.nzl = slab_begin(p->nz, nranks, rank + 1) - c.z0;
   // row pitch of the half spectrum: NX/2+1 complex, padded to a multiple of 8 (128 bytes) so that
   // rocFFT's strided y pass and the mode-parallel z sweeps work on aligned rows; the pad columns
   // are zero and stay zero (the transforms never touch them, the z solve maps 0 to 0)
@@ -281,7 +280,9 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   if (hipMemsetAsync(c.spec, 0, (size_t)c.nzl * p->ny * c.nxh * sizeof(double2), c.stream) != hipSuccess) { c.err = "hipMemsetAsync failed"; return bail(EKPNP_ERR_HIP); }
   const size_t nmodes = (size_t)p->ny * c.nxh;
   // slabs: the full table of their local rows; one context: only the rows its z solve restarts from
-  const size_t cprime_rows = !slab ? (size_t)(p->nz - 2) / TRI_CHECK + 1 : (size_t)c.nzl + 2;
+  int rows_max = 0;  // the longest block of unknown rows among the ranks (set-up of their (u_1, u_m))
+  for (int r = 0; r < nranks; ++r) rows_max = slab_rows(p->nz, nranks, r) > rows_max ? slab_rows(p->nz, nranks, r) : rows_max;
+  const size_t cprime_rows = !slab ? (size_t)(p->nz - 2) / TRI_CHECK + 1 : (size_t)rows_max + 2;
   if ((rc = dev_alloc(c, (void**)&c.cprime, cprime_rows * nmodes * sizeof(double)))) return bail(rc);
   {
     const double vw[4] = {p->voltage, p->voltage, p->voltage2, p->voltage2};  // pairs: the two-nodes-per-lane phi/E kernel loads 16 bytes
@@ -303,8 +304,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
     c.slab_m = row_e - c.slab_row_a + 1;
     if ((rc = dev_alloc(c, (void**)&c.slab_u, (size_t)c.slab_m * nmodes * sizeof(double)))) return bail(rc);
     if ((rc = dev_alloc(c, (void**)&c.slab_w, (size_t)c.slab_m * nmodes * sizeof(double)))) return bail(rc);
-    for (int k = 0; k < 2; ++k)
-      if ((rc = dev_alloc(c, (void**)&c.u1um[k], 2 * nmodes * sizeof(double)))) return bail(rc);
+    if ((rc = dev_alloc(c, (void**)&c.u1um, (size_t)nranks * 2 * nmodes * sizeof(double)))) return bail(rc);
     if ((rc = dev_alloc(c, (void**)&c.edge_local, 4 * nmodes * sizeof(double)))) return bail(rc);
     if ((rc = dev_alloc(c, (void**)&c.edge_all, (size_t)nranks * 4 * nmodes * sizeof(double)))) return bail(rc);
   }
@@ -362,8 +362,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   drop_graph(c);
   if (c.slab_u) (void)hipFree(c.slab_u);
   if (c.slab_w) (void)hipFree(c.slab_w);
-  if (c.u1um[0]) (void)hipFree(c.u1um[0]);
-  if (c.u1um[1]) (void)hipFree(c.u1um[1]);
+  if (c.u1um) (void)hipFree(c.u1um);
   if (c.edge_local) (void)hipFree(c.edge_local);
   if (c.edge_all) (void)hipFree(c.edge_all);
   if (c.phi_old) (void)hipFree(c.phi_old);

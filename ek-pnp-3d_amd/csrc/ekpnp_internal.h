@@ -58,6 +58,15 @@ constexpr int TILE = Q * 64;
 constexpr int TRI_CHECK = EKPNP_TRI_CHECK;  // the z solves keep every TRI_CHECK-th row of c' and of d' (poisson.hip TRI_BS)
 __host__ __device__ inline long long pop_xoff(int x) { return (long long)(x >> 6) * TILE + (x & 63); }
 
+// z partition of the slabs: rank r owns planes [slab_begin(r), slab_begin(r+1)); sizes differ by at most one
+// plane (NZ is typically 2^k + 1 in the reference's runs: LBM.h:35,37, main.cu:112), walls on ranks 0 and P-1
+inline int slab_begin(int nz, int nranks, int r) { return (int)((long long)r * nz / nranks); }
+// unknown rows of the global z system that rank r owns (the plates carry none)
+inline int slab_rows(int nz, int nranks, int r) {
+  const int z0 = slab_begin(nz, nranks, r), z1 = slab_begin(nz, nranks, r + 1);
+  return (z1 - z0) - (z0 == 0 ? 1 : 0) - (z1 == nz ? 1 : 0);
+}
+
 // Everything a kernel needs, passed by value.
 struct KArgs {
   // population buffers, tiled as above; B may also be the 2-plane staging buffer (same layout)
@@ -195,7 +204,7 @@ struct Ctx {
   int slab_row_a = 0, slab_m = 0;  // first unknown row (local plane) and number of unknown rows
   double* slab_u = nullptr;        // u = A^-1 e_1, [slab_m][modes]
   double* slab_w = nullptr;        // forward elimination of e_1, [slab_m][modes]
-  double* u1um[2] = {};            // (u_1, u_m) of an edge slab (nzl-1 rows) / a middle slab (nzl rows)
+  double* u1um = nullptr;          // (u_1, u_m) of EVERY rank's block, [nranks][2][modes] (slabs may differ by one plane)
   double* edge_local = nullptr;    // [4][modes]
   double* edge_all = nullptr;      // [nranks][4][modes]
   double* phi_old = nullptr;       // PB relaxation state (ekpnp_pbe_begin/end)

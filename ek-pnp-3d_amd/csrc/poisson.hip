@@ -490,21 +490,21 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __r
 // Interface i sits between slab i and i+1: X_i = x_last(slab i), Y_i = x_first(slab i+1):
 //   um_i X_{i-1} + X_i + u1_i Y_i             = p_last(i)
 //   u1_{i+1} X_i + Y_i + um_{i+1} Y_{i+1}     = p_first(i+1)
-// u1/um of slab j are those of its row count: type 0 (first/last slab, nzl-1 rows) or 1 (nzl).
+// u1/um of slab j are those of ITS row count (slabs may differ by a plane; the edge slabs lose their plate).
 constexpr int MAXR = 16;
 // the interface system is tiny (2(P-1) unknowns per mode) but wants per-thread arrays; it has a
 // kernel of its own so that the sweep below keeps its registers and needs no scratch memory
 // (fused, the sweep carried 1.8 KB of scratch per lane: 0.650 ms on a 512^3 slab against 0.458 + 0.006 ms
 // split, profiles/r02_slab_after_kernel_stats.csv)
-__global__ void k_slab_interface(PArgs a, int rank, int nranks, const double* __restrict__ edges_all, const double* __restrict__ u1um_edge,
-                                 const double* __restrict__ u1um_mid, double* __restrict__ g) {
+__global__ void k_slab_interface(PArgs a, int rank, int nranks, const double* __restrict__ edges_all, const double* __restrict__ u1um_all,
+                                 double* __restrict__ g) {
   const int md = blockIdx.x * blockDim.x + threadIdx.x;
   const long long ms = (long long)a.ny * a.nxh;
   if (md >= ms) return;
   const int ni = nranks - 1;
   double u1[MAXR], um[MAXR];
   for (int j = 0; j < nranks; ++j) {
-    const double* t = (j == 0 || j == nranks - 1) ? u1um_edge : u1um_mid;
+    const double* t = u1um_all + (long long)j * 2 * ms;  // (u_1, u_m) of rank j's block (its own row count)
     u1[j] = t[md];
     um[j] = t[ms + md];
   }
@@ -632,29 +632,46 @@ int build_cprime(Ctx& c) {
     return e == hipErrorOutOfMemory ? EKPNP_ERR_NOMEM : EKPNP_ERR_HIP;
   };
   // single context: rows 1..nz-2 of the global system; slab: rows 1..nzl of a local block
-  const int rows_nz = !c.slab ? c.p.nz : c.nzl + 2;
+  int rows_nz = c.p.nz;
+  if (c.slab) {  // rows 1..(longest block among the ranks): the set-up below needs every rank's (u_1, u_m)
+    rows_nz = 0;
+    for (int r = 0; r < c.nranks; ++r) rows_nz = slab_rows(c.p.nz, c.nranks, r) + 2 > rows_nz ? slab_rows(c.p.nz, c.nranks, r) + 2 : rows_nz;
+  }
   hipLaunchKernelGGL(k_build_cprime, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.p.nx, c.p.ny, rows_nz, c.nxh, c.p.Lx,
                      c.p.Ly, c.p.dz, c.slab ? 1 : TRI_BS);
   note_launch(c, "k_build_cprime");
   if (take_launch_error(c) != hipSuccess) return EKPNP_ERR_HIP;  // message names the kernel
-  hipError_t e = hipSuccess;
   if (c.slab) {
-    const bool edge_rank = (c.rank == 0 || c.rank == c.nranks - 1);
-    hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, c.slab_m, nm, c.slab_u,
-                       edge_rank ? c.u1um[0] : c.u1um[1], c.slab_w);
-    note_launch(c, "k_slab_unit_response");
-    if (take_launch_error(c) != hipSuccess) return EKPNP_ERR_HIP;
-    // (u_1, u_m) of the other slab type, through a scratch vector (set-up only)
-    const int m_other = edge_rank ? c.nzl : c.nzl - 1;
+    // (u_1, u_m) of every rank's block - they depend on the block's row count only, so each distinct
+    // count is computed once (set-up only); this rank's own run also fills its u and w tables
+    const int np = c.nranks;
+    int rows_max = 0;
+    for (int r = 0; r < np; ++r) rows_max = slab_rows(c.p.nz, np, r) > rows_max ? slab_rows(c.p.nz, np, r) : rows_max;
     double* tmp = nullptr;
-    if ((e = hipMalloc((void**)&tmp, (size_t)m_other * nm * sizeof(double))) != hipSuccess) return hipfail("scratch allocation for the slab unit response", e);
-    hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, m_other, nm, tmp,
-                       edge_rank ? c.u1um[1] : c.u1um[0], (double*)nullptr);
-    note_launch(c, "k_slab_unit_response");
-    const hipError_t el = take_launch_error(c);
+    hipError_t e = hipMalloc((void**)&tmp, (size_t)rows_max * nm * sizeof(double));
+    if (e != hipSuccess) return hipfail("scratch allocation for the slab unit response", e);
+    int rc = EKPNP_OK;
+    for (int r = 0; r < np && rc == EKPNP_OK; ++r) {
+      const int m = slab_rows(c.p.nz, np, r);
+      double* slot = c.u1um + (size_t)r * 2 * nm;
+      int same = -1;
+      for (int q = 0; q < r; ++q)
+        if (q != c.rank && slab_rows(c.p.nz, np, q) == m) { same = q; break; }
+      if (r == c.rank) {
+        hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, m, nm, c.slab_u, slot, c.slab_w);
+        note_launch(c, "k_slab_unit_response");
+      } else if (same >= 0) {
+        e = hipMemcpyAsync(slot, c.u1um + (size_t)same * 2 * nm, (size_t)2 * nm * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
+        if (e != hipSuccess) rc = hipfail("copy of a unit response", e);
+      } else {
+        hipLaunchKernelGGL(k_slab_unit_response, dim3((nm + 127) / 128), dim3(128), 0, c.stream, c.cprime, m, nm, tmp, slot, (double*)nullptr);
+        note_launch(c, "k_slab_unit_response");
+      }
+      if (rc == EKPNP_OK && take_launch_error(c) != hipSuccess) rc = EKPNP_ERR_HIP;
+    }
     const hipError_t es = hipStreamSynchronize(c.stream);
     const hipError_t ef = hipFree(tmp);
-    if (el != hipSuccess) return EKPNP_ERR_HIP;
+    if (rc) return rc;
     if (es != hipSuccess) return hipfail("slab unit response", es);
     if (ef != hipSuccess) return hipfail("hipFree of the unit-response scratch", ef);
   }
@@ -672,8 +689,7 @@ void launch_slab_reduce_correct(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
   // the edge buffer of this rank has been gathered and is free again: it takes (g_lo, g_hi)
-  hipLaunchKernelGGL(k_slab_interface, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.edge_all, c.u1um[0], c.u1um[1],
-                     c.edge_local);
+  hipLaunchKernelGGL(k_slab_interface, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.edge_all, c.u1um, c.edge_local);
   note_launch(c, "k_slab_interface");
   hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.edge_local, c.slab_w);
   note_launch(c, "k_slab_reduce_correct");

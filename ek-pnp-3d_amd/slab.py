@@ -35,13 +35,12 @@ from .solver import FIELDS, Params, Solver
 
 
 def slab_extent(nz: int, rank: int, nranks: int):
-    """(first plane, number of planes) owned by `rank` (same rule as ekpnp_create_slab)."""
-    if nz % nranks:
-        raise ValueError("nz must be divisible by the number of slabs")
-    n = nz // nranks
-    if nranks > 1 and n < 4:
+    """(first plane, number of planes) owned by `rank`: planes [rank*nz//nranks, (rank+1)*nz//nranks),
+    the same rule as ekpnp_create_slab (slabs differ by at most one plane)."""
+    if nranks > 1 and nz // nranks < 4:
         raise ValueError("each z slab needs at least 4 planes")
-    return rank * n, n
+    z0 = rank * nz // nranks
+    return z0, (rank + 1) * nz // nranks - z0
 
 
 class _DevArray:

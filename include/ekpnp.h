@@ -96,11 +96,12 @@ int ekpnp_default_params(ekpnp_params* p, int nx, int ny, int nz);
  * plan and the wavenumber tables) for a whole lattice on the current device. */
 int ekpnp_create(const ekpnp_params* p, ekpnp_ctx** out);
 
-/* z-slab variant (no reference counterpart): rank `rank` of
- * `nranks` owns planes [rank*nz/nranks, (rank+1)*nz/nranks).  nz % nranks must
- * be 0 and every slab needs >= 4 planes.  Halo transport is the caller's job,
- * through ekpnp_halo_* below.  nranks == 1 is allowed (the ring closes on the same
- * rank): the whole multi-rank call sequence on one GPU. */
+/* z-slab variant (no reference counterpart): rank `rank` of `nranks` owns planes
+ * [rank*nz/nranks, (rank+1)*nz/nranks) (integer division: the slabs differ by at most one plane, so
+ * the reference's usual NZ = 2^k + 1 decomposes over any number of GPUs); every slab needs >= 4
+ * planes, at most 16 slabs.  Halo transport: the library's own (ekpnp_slab_attach_comm,
+ * ekpnp_group_* below) or the caller's, through ekpnp_halo_*.  nranks == 1 is allowed (the ring
+ * closes on the same rank): the whole multi-rank call sequence on one GPU. */
 int ekpnp_create_slab(const ekpnp_params* p, int rank, int nranks, ekpnp_ctx** out);
 
 /* Replaces main.cu:264-290 (cudaFree / cufftDestroy / cudaDeviceReset). */

@@ -60,8 +60,9 @@ def test_invalid_arguments_return_errors_not_exit(pkg):
     assert b"n_lattices" in lib.ekpnp_last_error(None)
     p.n_lattices = 3  # Ra != 0 with 3 lattices is not parity-safe
     assert lib.ekpnp_create(C.byref(p), C.byref(h)) == 1
-    p = pkg.default_params(8, 8, 9)
-    assert lib.ekpnp_create_slab(C.byref(p), 0, 2, C.byref(h)) == 1  # nz % nranks
+    p = pkg.default_params(8, 8, 7)
+    assert lib.ekpnp_create_slab(C.byref(p), 0, 2, C.byref(h)) == 1  # slabs of 3 and 4 planes: too thin
+    assert b"4 planes" in lib.ekpnp_last_error(None)
     p = pkg.default_params(8, 70000, 8)
     assert lib.ekpnp_create(C.byref(p), C.byref(h)) == 1
     assert b"ny" in lib.ekpnp_last_error(None)

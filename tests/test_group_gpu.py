@@ -374,3 +374,20 @@ def test_group_with_fewer_lattices_vs_oracle(pkg, O, nl):
     skip = ("T",) if nl == 3 else ("T", "c", "cn", "phi", "E")
     groups = {k: v for k, v in O.GROUPS.items() if k not in skip}
     _check(O, got, want, groups, f"{nl} lattices")
+
+
+@pytest.mark.parametrize("shape,nslabs,in_place", [((24, 6, 51), 2, 0), ((24, 6, 52), 3, 1), ((70, 5, 65), 8, 0), ((16, 8, 33), 5, 0), ((20, 6, 131), 7, 1)])
+def test_uneven_slabs_vs_oracle(pkg, O, shape, nslabs, in_place):
+    """NZ not divisible by the number of slabs (the reference's usual NZ = 2^k + 1, LBM.h:35): the
+    slabs differ by one plane; every rank solves the interface system with each block's own
+    (u_1, u_m)."""
+    po = O.default_params(*shape)
+    po.pb_iterations = 10
+    ref = _oracle_run(O, po, 6)
+    p = _mirror(pkg, po)
+    p.in_place = in_place
+    with pkg.Group(p, nslabs, devices=[0] * nslabs) as g:
+        ext = [g.slab_extent(i) for i in range(nslabs)]
+        assert ext[0][0] == 0 and ext[-1][0] + ext[-1][1] == shape[2]
+        assert all(a[0] + a[1] == b[0] for a, b in zip(ext, ext[1:])) and max(e[1] for e in ext) - min(e[1] for e in ext) == 1
+        _drive(O, g, po, ref, 6)

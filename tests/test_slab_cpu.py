@@ -32,7 +32,10 @@ def test_slab_extent_rules(pkg):
 
     assert slab_extent(512, 0, 1) == (0, 512)
     assert [slab_extent(1024, r, 8) for r in (0, 3, 7)] == [(0, 128), (384, 128), (896, 128)]
-    with pytest.raises(ValueError):
-        slab_extent(51, 0, 2)
+    # the reference's usual NZ = 2^k + 1: slabs differ by at most one plane and tile the channel
+    assert [slab_extent(51, r, 2) for r in (0, 1)] == [(0, 25), (25, 26)]
+    ext = [slab_extent(513, r, 8) for r in range(8)]
+    assert ext[0][0] == 0 and ext[-1][0] + ext[-1][1] == 513
+    assert all(a[0] + a[1] == b[0] for a, b in zip(ext, ext[1:])) and {e[1] for e in ext} == {64, 65}
     with pytest.raises(ValueError):
         slab_extent(12, 0, 4)

@@ -262,6 +262,15 @@ struct TextIoArgs { const char* path; int append; double time; int first; int ki
 int io_write_text_part(Ctx&, const TextIoArgs&);
 int io_read_data_part(Ctx&, const char* path, double* time);
 
+// lossless state file "EKPNPST1" (fields only; io.hip and the group variant in slab_team.hip)
+struct StateHeader {
+  char magic[8];
+  int32_t nx, ny, nz, z0, nzl, nfields;
+  double time;
+};
+static_assert(sizeof(StateHeader) == 40, "state header layout");
+constexpr size_t STATE_CHUNK = (size_t)4 << 20;  // doubles per bounce-buffer transfer (32 MiB)
+
 // full checkpoint (io.hip), pieces shared with the group variant in slab_team.hip
 struct CkptHeader {
   char magic[8];

@@ -207,16 +207,6 @@ extern "C" int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time) {
 }
 
 // ---- lossless binary state (no reference counterpart beyond the save_data_end / read_data pair) ----
-namespace {
-struct StateHeader {
-  char magic[8];
-  int32_t nx, ny, nz, z0, nzl, nfields;
-  double time;
-};
-static_assert(sizeof(StateHeader) == 40, "state header layout");
-constexpr size_t STATE_CHUNK = (size_t)4 << 20;  // doubles per bounce-buffer transfer (32 MiB)
-}  // namespace
-
 extern "C" int ekpnp_save_state(ekpnp_ctx* ctx, const char* path, double time) {
   NEEDCTX(ctx);
   if (!path) return fail(c, "NULL path");

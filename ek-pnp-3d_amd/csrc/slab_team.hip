@@ -495,9 +495,8 @@ static int own_team(Ctx& c, Team** T) {
     int rc0_ = own_team(c, &T);      \
     if (rc0_) return rc0_;           \
   }
-static int lift(Ctx& c, Team& T, int rc) {
-  if (rc && c.err.empty()) c.err = T.err;
-  else if (rc) c.err = T.err.empty() ? c.err : T.err;
+static int lift(Ctx& c, Team& T, int rc) {  // the attached context reports the team's message as its own
+  if (rc && !T.err.empty()) c.err = T.err;
   return rc;
 }
 
@@ -755,12 +754,8 @@ static int group_diag(Team& T, bool is_max, double* out) {
   for (size_t i = 0; i < T.m.size(); ++i) {
     int rc = use(T, (int)i);
     if (rc) return rc;
-    ekpnp_ctx* m = T.m[i];
-    Team* keep = m->c.team;
-    m->c.team = nullptr;  // the slab's own value, not a team reduction
-    rc = is_max ? ekpnp_umax(m, &v[i]) : ekpnp_current(m, &v[i]);
-    m->c.team = keep;
-    if (rc) { T.err = "slab " + std::to_string(i) + ": " + m->c.err; return rc; }
+    // a group member's ekpnp_current / ekpnp_umax return the slab's own value (no team reduction)
+    TSLAB(T, (int)i, is_max ? ekpnp_umax(T.m[i], &v[i]) : ekpnp_current(T.m[i], &v[i]));
   }
   return team_reduce(T, v, is_max, out);
 }
@@ -820,16 +815,6 @@ extern "C" int ekpnp_group_read_data(ekpnp_group* g, const char* path, double* t
 }
 
 // whole-lattice EKPNPST1 file (same format a single context writes: z0 = 0, nz_local = nz)
-namespace {
-struct StateHeader {
-  char magic[8];
-  int32_t nx, ny, nz, z0, nzl, nfields;
-  double time;
-};
-static_assert(sizeof(StateHeader) == 40, "state header layout");
-constexpr size_t STATE_CHUNK = (size_t)4 << 20;
-}  // namespace
-
 extern "C" int ekpnp_group_save_state(ekpnp_group* g, const char* path, double time) {
   NEEDGROUP(g);
   if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }

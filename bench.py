@@ -471,6 +471,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     n_launch, k_ms, k_nodes = sol.kernel_timing_get()
+    n_solves, poisson_ms = sol.phase_timing_get()
     sol.kernel_timing(False)
 
     if dist is not None:
@@ -535,6 +536,14 @@ def main():
                 "step_roofline_frac": round(b_alg_step(nl) * mlups / world * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
                 "device_bytes": sol.device_bytes(),
                 "finite": finite,
+                # HIP events on the context's stream inside the timed region: the collide sweep of the interior
+                # planes, the Poisson solve (on slabs: stage 1 to stage 3, exchanges included), and what is
+                # left of the step (wall planes, halo pack / unpack, dependency gaps)
+                "phases_ms_per_step": {
+                    "collide_bulk": round(k_ms / max(1, args.steps), 4),
+                    "poisson": round(poisson_ms / max(1, n_solves), 4),
+                    "rest": round(dt / args.steps * 1e3 - k_ms / max(1, args.steps) - poisson_ms / max(1, n_solves), 4),
+                },
             },
             "roofline": {
                 "kernel": "k_collide_bulk",

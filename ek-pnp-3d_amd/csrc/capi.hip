@@ -375,6 +375,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (c.have_fwd) hipfftDestroy(c.plan_fwd);
   if (c.have_inv) hipfftDestroy(c.plan_inv);
   for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : c.ev_poisson) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
   delete ctx;
   return EKPNP_OK;
@@ -501,7 +502,27 @@ extern "C" int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per
 // ------------------------------------------------------------------------------------------
 // Poisson
 
+// measurement hook: HIP events around a Poisson solve (stage 1 .. stage 3 on slabs), summed by ekpnp_phase_timing_get
+static int poisson_timing_mark(Ctx& c, bool begin) {
+  if (!c.timing) return EKPNP_OK;
+  if (begin) {
+    if (c.evp_used == c.ev_poisson.size()) {
+      hipEvent_t a, b;
+      HIPCHK(c, hipEventCreate(&a));
+      HIPCHK(c, hipEventCreate(&b));
+      c.ev_poisson.emplace_back(a, b);
+    }
+    HIPCHK(c, hipEventRecord(c.ev_poisson[c.evp_used].first, c.stream));
+  } else if (c.evp_used < c.ev_poisson.size()) {
+    HIPCHK(c, hipEventRecord(c.ev_poisson[c.evp_used].second, c.stream));
+    c.evp_used++;
+  }
+  return EKPNP_OK;
+}
+
 static int poisson_single(Ctx& c) {
+  int trc = poisson_timing_mark(c, true);
+  if (trc) return trc;
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
   FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec()));
@@ -509,7 +530,7 @@ static int poisson_single(Ctx& c) {
   FFTCHK(c, hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out()));
   launch_phi_efield(c);
   LAUNCHCHK(c);
-  return EKPNP_OK;
+  return poisson_timing_mark(c, false);
 }
 
 // A right-hand side the collide wrote from its registers is only trusted when both concentration
@@ -821,6 +842,7 @@ extern "C" int ekpnp_kernel_timing_enable(ekpnp_ctx* ctx, int enable) {
   HIPCHK(c, hipStreamSynchronize(c.stream));
   c.timing = enable != 0;
   c.ev_used = 0;
+  c.evp_used = 0;
   return EKPNP_OK;
 }
 
@@ -837,6 +859,21 @@ extern "C" int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* 
   if (total_ms) *total_ms = tot;
   if (nodes_per_launch) *nodes_per_launch = c.timed_nodes;
   c.ev_used = 0;
+  return EKPNP_OK;
+}
+
+extern "C" int ekpnp_phase_timing_get(ekpnp_ctx* ctx, int* n_solves, double* poisson_ms) {
+  NEEDCTX(ctx);
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  double tot = 0.0;
+  for (size_t i = 0; i < c.evp_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c.ev_poisson[i].first, c.ev_poisson[i].second));
+    tot += ms;
+  }
+  if (n_solves) *n_solves = (int)c.evp_used;
+  if (poisson_ms) *poisson_ms = tot;
+  c.evp_used = 0;
   return EKPNP_OK;
 }
 
@@ -947,6 +984,10 @@ extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   distrust_bound_rhs(c);
+  {
+    int trc = poisson_timing_mark(c, true);
+    if (trc) return trc;
+  }
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
   FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec()));
@@ -986,5 +1027,5 @@ extern "C" int ekpnp_poisson_stage3(ekpnp_ctx* ctx) {
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   launch_phi_efield(c);
   LAUNCHCHK(c);
-  return EKPNP_OK;
+  return poisson_timing_mark(c, false);
 }

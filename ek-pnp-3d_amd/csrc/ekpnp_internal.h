@@ -227,6 +227,8 @@ struct Ctx {
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t ev_used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_poisson;  // the same around every Poisson solve (all its stages)
+  size_t evp_used = 0;
   long long timed_nodes = 0;
   std::string err;
 

@@ -110,6 +110,7 @@ def load_library():
         "ekpnp_local_extent": (i32, [ctx, C.POINTER(i32), C.POINTER(i32)]),
         "ekpnp_kernel_timing_enable": (i32, [ctx, i32]),
         "ekpnp_kernel_timing_get": (i32, [ctx, C.POINTER(i32), pd, C.POINTER(C.c_int64)]),
+        "ekpnp_phase_timing_get": (i32, [ctx, C.POINTER(i32), pd]),
         "ekpnp_device_bytes": (sz, [ctx]),
         "ekpnp_graph_state": (i32, [ctx]),
         "ekpnp_debug_sync_enabled": (i32, []),
@@ -411,6 +412,12 @@ class Solver:
     # -- measurement ------------------------------------------------------------------------
     def kernel_timing(self, enable: bool):
         self._ck(self._L.ekpnp_kernel_timing_enable(self._h, int(enable)))
+
+    def phase_timing_get(self):
+        """(number of Poisson solves bracketed since the last call, their summed duration in ms)"""
+        n, ms = C.c_int(), C.c_double()
+        self._ck(self._L.ekpnp_phase_timing_get(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def kernel_timing_get(self):
         n, ms, nodes = C.c_int(), C.c_double(), C.c_int64()

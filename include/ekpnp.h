@@ -225,6 +225,9 @@ int ekpnp_save_scalar(ekpnp_ctx* ctx, const char* name, int field_id, unsigned n
 int ekpnp_kernel_timing_enable(ekpnp_ctx* ctx, int enable);
 int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* total_ms,
                             int64_t* nodes_per_launch);
+/* While timing is enabled every Poisson solve (all its stages, on slabs from stage 1 to stage 3
+ * including the exchanges in between) is bracketed the same way; this returns and resets the sum. */
+int ekpnp_phase_timing_get(ekpnp_ctx* ctx, int* n_solves, double* poisson_ms);
 size_t ekpnp_device_bytes(const ekpnp_ctx* ctx);
 /* Streaming-copy rate of this device in GB/s (read + write bytes / time) of a plain contiguous
  * copy of `bytes` bytes on the context's stream: the secondary denominator SURVEY.md 8(d) asks

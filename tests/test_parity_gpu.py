@@ -572,3 +572,29 @@ def test_bench_start_profile_from_the_product_vs_gouy_chapman(pkg):
     assert prof["phi"][0] == p.voltage and prof["phi"][-1] == p.voltage2
     assert np.allclose(prof["c"] * prof["cn"], p.chargeinf**2, rtol=1e-9)  # Boltzmann
     assert abs(prof["phi"][256]) < 1e-7  # the double layers do not reach the mid-plane (2 zeta exp(-128/9.2) ~ 1e-8)
+
+
+@pytest.mark.parametrize("nz,nslabs", [(130, 1), (258, 2)])
+def test_large_lattice_kernels_vs_oracle(pkg, O, nz, nslabs):
+    """The kernels only large lattices use - the two-nodes-per-lane phi/E kernel (rows of a multiple
+    of 128 nodes, >= 2 M nodes per context), 16-plane marching, the serial Thomas z solve - against
+    the oracle: 128x128x130 in one context, 128x128x258 in two slabs (the same kernels with the phi
+    halo planes and the distributed z solve)."""
+    po = O.default_params(128, 128, nz)
+    po.pb_iterations = 3
+    orc = O.Oracle(po)
+    orc.initialization()
+    start = O.perturb_fields(po, orc.fields())
+    orc.set_fields(start); orc.fast_poisson()
+    pois = orc.fields()
+    orc.init_equilibrium(); orc.step(3)
+    want = orc.fields()
+    orc.close()
+    p = _mirror(pkg, po)
+    with (pkg.Solver(p) if nslabs == 1 else pkg.Group(p, nslabs, devices=[0] * nslabs)) as s:
+        s.initialization()
+        s.set_fields(start); s.fast_Poisson()
+        e0 = O.rel_l2(s.fields(), pois, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
+        s.init_equilibrium(); s.step(3)
+        e3 = O.rel_l2(s.fields(), want)
+    _assert_all([("poisson", e0), (3, e3)], name=f"large_lattice_{nz}_{nslabs}")

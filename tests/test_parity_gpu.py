@@ -598,3 +598,40 @@ def test_large_lattice_kernels_vs_oracle(pkg, O, nz, nslabs):
         s.init_equilibrium(); s.step(3)
         e3 = O.rel_l2(s.fields(), want)
     _assert_all([("poisson", e0), (3, e3)], name=f"large_lattice_{nz}_{nslabs}")
+
+
+@pytest.mark.parametrize("case", ["cfg2", "cfg3_width"])
+def test_full_size_vs_oracle(pkg, O, case):
+    """Against the oracle itself at BASELINE sizes.  cfg2 at its FULL size (256x256x256, f + h + hn,
+    Ra = 0: 16.8 M nodes) and cfg3's full 512x512 planes, all four lattices, on 130 planes (34 M nodes;
+    the full 512 planes would need 250 GB of host memory for the oracle - the z extent of cfg3 is
+    covered by test_cfg3_maximum_size_translation_invariance): one Poisson solve and two steps from
+    the bench's start state."""
+    import bench
+
+    shape, nl = ((256, 256, 256), 3) if case == "cfg2" else ((512, 512, 130), 4)
+    po = O.default_params(*shape)
+    if nl == 3:
+        po.Ra = 0.0
+    p = _mirror(pkg, po)
+    p.n_lattices = nl
+    with pkg.Solver(p) as s:
+        prof, _ = bench.pb_profile_from_product(pkg, p)
+        bench.product_pb_state(s, p, prof)
+        bench.apply_perturbation(s, None, p)
+        start = s.fields()
+        s.fast_Poisson()
+        pois = {k: s.get_field(k) for k in ("phi", "Ex", "Ey", "Ez")}
+        s.init_equilibrium()
+        s.step(2)
+        got = s.fields()
+    orc = O.Oracle(po)
+    orc.set_fields(start)
+    del start
+    orc.fast_poisson()
+    e0 = O.rel_l2(pois, {k: orc.field(k) for k in pois}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
+    orc.init_equilibrium()
+    orc.step(2)
+    e2 = O.rel_l2(got, orc.fields(), {k: v for k, v in O.GROUPS.items() if nl == 4 or k != "T"})
+    orc.close()
+    _assert_all([("poisson", e0), (2, e2)], name=f"{case}_full_size_vs_oracle")

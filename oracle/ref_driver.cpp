@@ -26,7 +26,8 @@
  *        ref_driver <outdir> io <in.bin> <tag>          -> upload fields; the reference's own
  *            save_data_tecplot (2 zones), save_data_end, record_umax and current() on them
  *        --set name=value writes a __constant__/__device__ physics symbol of LBM.h at run time
- *        (exf uw chargeinf voltage voltage2 Ext Ra TH): no source edit, hipMemcpyToSymbol only.
+ *        (exf uw chargeinf voltage voltage2 Ext Ra TH K Kn nu D diffu diffun eps rho0 V VC VCn VT PB_omega):
+ *        no source edit, hipMemcpyToSymbol only.
  * The phi columns let the tests measure the reference's DC-mode leak (poisson.cu:177) of every
  * single Poisson solve: phi_ref - phi_exact is one constant per solve on the interior.
  */
@@ -163,14 +164,12 @@ static void set_symbol(const std::string& kv) {
   std::string name = kv.substr(0, eq);
   double v = atof(kv.c_str() + eq + 1);
   hipError_t e = hipErrorInvalidValue;
-  if (name == "exf") e = hipMemcpyToSymbol(HIP_SYMBOL(exf), &v, sizeof(double));
-  else if (name == "uw") e = hipMemcpyToSymbol(HIP_SYMBOL(uw), &v, sizeof(double));
-  else if (name == "chargeinf") e = hipMemcpyToSymbol(HIP_SYMBOL(chargeinf), &v, sizeof(double));
-  else if (name == "voltage") e = hipMemcpyToSymbol(HIP_SYMBOL(voltage), &v, sizeof(double));
-  else if (name == "voltage2") e = hipMemcpyToSymbol(HIP_SYMBOL(voltage2), &v, sizeof(double));
-  else if (name == "Ext") e = hipMemcpyToSymbol(HIP_SYMBOL(Ext), &v, sizeof(double));
-  else if (name == "Ra") e = hipMemcpyToSymbol(HIP_SYMBOL(Ra), &v, sizeof(double));
-  else if (name == "TH") e = hipMemcpyToSymbol(HIP_SYMBOL(TH), &v, sizeof(double));
+#define SETSYM(sym) else if (name == #sym) e = hipMemcpyToSymbol(HIP_SYMBOL(sym), &v, sizeof(double))
+  if (false) {}
+  SETSYM(exf); SETSYM(uw); SETSYM(chargeinf); SETSYM(voltage); SETSYM(voltage2); SETSYM(Ext); SETSYM(Ra); SETSYM(TH);
+  SETSYM(K); SETSYM(Kn); SETSYM(nu); SETSYM(D); SETSYM(diffu); SETSYM(diffun); SETSYM(eps); SETSYM(rho0);
+  SETSYM(V); SETSYM(VC); SETSYM(VCn); SETSYM(VT); SETSYM(PB_omega);
+#undef SETSYM
   if (e != hipSuccess) { fprintf(stderr, "cannot set %s\n", name.c_str()); exit(2); }
   printf("set %s = %.17g\n", name.c_str(), v);
 }

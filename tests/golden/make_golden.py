@@ -150,6 +150,67 @@ def extra_grid(outdir, grid):
     print("golden vectors of grid", grid, "written to", outdir)
 
 
+# G8: every physics knob away from its default and the two plates at DIFFERENT zeta potentials (all other
+# goldens have voltage == voltage2, so a swapped plate could not be seen); written into the reference's
+# __constant__/__device__ symbols at run time (ref_driver --set), LBM.h itself is not edited
+ASYM = {"voltage": -3.1e-3, "voltage2": -6.9e-3, "Ext": 2.3e4, "TH": 0.7, "Ra": 1.7, "K": 3.9e-7, "Kn": -4.6e-7, "diffu": 1.2e-8,
+        "diffun": 0.8e-8, "nu": 0.7e-6, "D": 1.1e-6, "exf": 2.0e7, "uw": 5.0e-4, "VC": 2.0e-6, "VCn": 0.5e-6, "V": 0.1, "VT": 0.07,
+        "chargeinf": 0.012, "eps": 7.5e-10}
+
+
+def asym_case(outdir, grid):
+    """G8 on the default grid ("50x8x51") or an extra one: initialization() + 1/5/20 steps of the x-y uniform
+    run and the perturbed 3-D run 0/1/30 steps, all with the ASYM physics."""
+    nx, ny, nz = (int(v) for v in grid.split("x"))
+    set_grid(nx, ny, nz)
+    os.makedirs(outdir, exist_ok=True)
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver" + ("" if grid == "50x8x51" else "_" + grid))
+    tmp = tempfile.mkdtemp()
+    sets = []
+    for k, v in ASYM.items():
+        sets += ["--set", f"{k}={v!r}"]
+
+    def run(*args):
+        print("+", os.path.basename(drv), *sets, *args, flush=True)
+        subprocess.check_call([drv, tmp, *sets, *args])
+
+    def trace(path, n):
+        return np.fromfile(path, dtype=np.float64).reshape(n, 2, NZ)
+
+    p = O.default_params(NX, NY, NZ)
+    if grid == "50x8x51":
+        p.Lx, p.Ly, p.Lz = 0.5e-6, 0.08e-6, 0.5e-6
+    for k, v in ASYM.items():
+        setattr(p, k, v)
+    marks1 = (1, 5, 20)
+    run("init", "a1", *[str(m) for m in marks1])
+    g = {"grid": np.array([NX, NY, NZ]), "param_names": np.array(list(ASYM)), "param_values": np.array(list(ASYM.values())),
+         "a1_marks": np.array(marks1)}
+    init = read_bin(os.path.join(tmp, "a1_init.bin"))
+    for tag, f in [("init", init)] + [(f"step{m}", read_bin(os.path.join(tmp, f"a1_step{m}.bin"))) for m in marks1]:
+        for k, v in f.items():
+            g[f"a1_{tag}_{k}"] = v
+    g["a1_current"] = np.array([read_current(os.path.join(tmp, f"a1_step{m}.bin")) for m in marks1])
+    g["a1_init_trace"] = trace(os.path.join(tmp, "a1_init_trace.bin"), 501)
+    g["a1_step_trace"] = trace(os.path.join(tmp, "a1_step_trace.bin"), marks1[-1])
+    start = O.perturb_fields(p, init)
+    inp = os.path.join(tmp, "a2_in.bin")
+    write_bin(inp, start)
+    marks2 = (1, 30)
+    run("fields", inp, "a2", *[str(m) for m in marks2])
+    g["a2_marks"] = np.array(marks2)
+    for k, v in start.items():
+        g["a2_input_" + k] = v
+    for m in (0,) + marks2:
+        f = read_bin(os.path.join(tmp, f"a2_step{m}.bin"))
+        for k, v in f.items():
+            g[f"a2_step{m}_{k}"] = v
+    g["a2_current"] = np.array([read_current(os.path.join(tmp, f"a2_step{m}.bin")) for m in marks2])
+    g["a2_step_trace"] = trace(os.path.join(tmp, "a2_step_trace.bin"), 1 + marks2[-1])
+    np.savez_compressed(os.path.join(outdir, f"ref_{grid}_g8_full.npz"), **g)
+    print("asymmetric-physics vectors of grid", grid, "written to", outdir)
+
+
 def main(outdir):
     set_grid(50, 8, 51)
     os.makedirs(outdir, exist_ok=True)
@@ -269,7 +330,10 @@ def main(outdir):
 
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/golden"
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and sys.argv[2] == "asym":
+        for g in sys.argv[3:]:
+            asym_case(out, g)
+    elif len(sys.argv) > 2:
         for g in sys.argv[2:]:
             extra_grid(out, g)
     else:

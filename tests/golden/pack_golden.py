@@ -318,7 +318,84 @@ def pack_extra(src, dst, grid):
     print(path, os.path.getsize(path), "bytes")
 
 
+def pack_asym(src, dst, grid):
+    """tests/golden/ref_<grid>_g8.npz: the asymmetric-physics case (make_golden.asym_case): parameters,
+    z profiles of the uniform run, inputs and y-row outputs of the perturbed run, every solve's DC constant."""
+    g = np.load(os.path.join(src, f"ref_{grid}_g8_full.npz"))
+    nx, ny, nz = (int(v) for v in g["grid"])
+    p = O.default_params(nx, ny, nz)
+    if grid == "50x8x51":
+        p.Lx, p.Ly, p.Lz = 0.5e-6, 0.08e-6, 0.5e-6
+    for k, v in zip(g["param_names"], g["param_values"]):
+        setattr(p, str(k), float(v))
+    L = O.lib()
+    out = {"grid": g["grid"], "param_names": g["param_names"], "param_values": g["param_values"], "ysel": np.array(YSEL),
+           "a1_marks": g["a1_marks"], "a2_marks": g["a2_marks"], "a1_current": g["a1_current"], "a2_current": g["a2_current"]}
+    o = O.Oracle(p)
+    o.gpu_initialization()
+    phi_old = o.field("phi").copy()
+    init_shifts, worst = [], 0.0
+    for i in range(501):
+        L.oracle_gpu_PBE(o._h)
+        o.fast_poisson(0.0)
+        s, dev = shift_of(g["a1_init_trace"][i], o.field("phi"))
+        worst = max(worst, dev)
+        init_shifts.append(s)
+        o.field("phi")[1:-1] += s
+        o.efield()
+        o.field("phi")[...] = p.PB_omega * o.field("phi") + (1 - p.PB_omega) * phi_old
+        phi_old = o.field("phi").copy()
+    o.init_equilibrium()
+    step_shifts = []
+    for k in range(int(g["a1_marks"][-1])):
+        o.stream_collide_save()
+        o.fast_poisson(0.0)
+        s, dev = shift_of(g["a1_step_trace"][k], o.field("phi"))
+        worst = max(worst, dev)
+        step_shifts.append(s)
+        o.field("phi")[1:-1] += s
+        o.efield()
+    print(f"{grid} G8 uniform run: max |phi_ref - phi_exact - shift|:", worst)
+    out["a1_init_shifts"], out["a1_step_shifts"] = np.array(init_shifts), np.array(step_shifts)
+    for tag in ["init"] + [f"step{m}" for m in g["a1_marks"]]:
+        for k in O.FIELDS:
+            out[f"a1_{tag}_{k}"] = g[f"a1_{tag}_{k}"][:, 0, 0].copy()
+    o = O.Oracle(p)
+    o.set_fields({k: g["a2_input_" + k] for k in O.FIELDS})
+    shifts, worst = [], 0.0
+    o.fast_poisson(0.0)
+    s, dev = shift_of(g["a2_step_trace"][0], o.field("phi"))
+    shifts.append(s)
+    worst = max(worst, dev)
+    o.field("phi")[1:-1] += s
+    o.efield()
+    o.init_equilibrium()
+    for k in range(int(g["a2_marks"][-1])):
+        o.stream_collide_save()
+        o.fast_poisson(0.0)
+        s, dev = shift_of(g["a2_step_trace"][k + 1], o.field("phi"))
+        worst = max(worst, dev)
+        shifts.append(s)
+        o.field("phi")[1:-1] += s
+        o.efield()
+    print(f"{grid} G8 perturbed run: max |phi_ref - phi_exact - shift|:", worst)
+    out["a2_shifts"] = np.array(shifts)
+    for k in ("rho", "c", "cn", "T", "ux", "uy", "uz"):
+        out["a2_input_" + k] = g["a2_input_" + k]
+    for m in [0] + list(g["a2_marks"]):
+        for k in O.FIELDS:
+            out[f"a2_step{m}_{k}"] = g[f"a2_step{m}_{k}"][:, YSEL, :].copy()
+    os.makedirs(dst, exist_ok=True)
+    path = os.path.join(dst, f"ref_{grid}_g8.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "asym":
+        for _g in sys.argv[4:]:
+            pack_asym(sys.argv[1], sys.argv[2], _g)
+        sys.exit(0)
     if len(sys.argv) > 3:
         for _g in sys.argv[3:]:
             pack_extra(sys.argv[1], sys.argv[2], _g)

@@ -447,3 +447,53 @@ def test_golden_extra_grid_G4_per_kernel_and_G5_poisson(O, grid):
     o.fast_poisson(float(g["g5_shift"]))
     got = {k: o.field(k)[:, ys, :] for k in ("phi", "Ex", "Ey", "Ez")}
     _check(O.rel_l2(got, {k: g["g5_out_" + k] for k in got}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]}), "poisson")
+
+
+# ---- G8: asymmetric physics -------------------------------------------------------------------
+# Every other golden has the two plates at the SAME zeta potential and the reference's default
+# physics.  G8 was made with voltage != voltage2 and every knob off its default (written into the
+# reference's __constant__/__device__ symbols at run time, ref_driver --set; LBM.h is not edited):
+# a plate swap, a K/Kn or diffu/diffun mix-up, a forgotten Ext / TH / Ra / uw / exf would show here.
+ASYM_GRIDS = ["50x8x51", "130x6x19"]
+
+
+def _asym(O, grid):
+    g = _need(f"ref_{grid}_g8.npz")
+    nx, ny, nz = (int(v) for v in g["grid"])
+    p = O.default_params(nx, ny, nz)
+    if grid == "50x8x51":
+        p.Lx, p.Ly, p.Lz = 0.5e-6, 0.08e-6, 0.5e-6
+    for k, v in zip(g["param_names"], g["param_values"]):
+        setattr(p, str(k), float(v))
+    assert p.voltage != p.voltage2 and p.K != -p.Kn and p.diffu != p.diffun
+    return g, p
+
+
+@pytest.mark.parametrize("grid", ASYM_GRIDS)
+def test_golden_G8_asymmetric_physics(O, grid):
+    g, p = _asym(O, grid)
+    o = O.Oracle(p)
+    o.initialization_shifts(g["a1_init_shifts"])
+    col = lambda d: {k: v[:, 0, 0] for k, v in d.items()}  # noqa: E731
+    _check(O.rel_l2(col(o.fields()), {k: g["a1_init_" + k] for k in O.FIELDS}, {k: v for k, v in O.GROUPS.items() if k != "u"}), "init")
+    o.init_equilibrium()
+    done = 0
+    for i, mark in enumerate(int(m) for m in g["a1_marks"]):
+        o.step_shifts(g["a1_step_shifts"][done:mark])
+        done = mark
+        _check(O.rel_l2(col(o.fields()), {k: g[f"a1_step{mark}_{k}"] for k in O.FIELDS}), f"uniform step {mark}")
+        want = float(g["a1_current"][i])
+        assert abs(o.current() - want) <= 1e-11 * abs(want), (mark, o.current(), want)
+    ys = list(g["ysel"])
+    o = O.Oracle(p)
+    o.gpu_initialization()
+    o.set_fields({k: g["a2_input_" + k] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+    sub = lambda d: {k: v[:, ys, :] for k, v in d.items()}  # noqa: E731
+    o.fast_poisson(float(g["a2_shifts"][0]))
+    _check(O.rel_l2(sub(o.fields()), {k: g["a2_step0_" + k] for k in O.FIELDS}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]}), "step 0")
+    o.init_equilibrium()
+    done = 0
+    for mark in (int(m) for m in g["a2_marks"]):
+        o.step_shifts(g["a2_shifts"][1 + done : 1 + mark])
+        done = mark
+        _check_race_aware(O, o, sub(o.fields()), {k: g[f"a2_step{mark}_{k}"] for k in O.FIELDS}, ys, f"perturbed step {mark}")

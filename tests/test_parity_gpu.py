@@ -635,3 +635,30 @@ def test_full_size_vs_oracle(pkg, O, case):
     e2 = O.rel_l2(got, orc.fields(), {k: v for k, v in O.GROUPS.items() if nl == 4 or k != "T"})
     orc.close()
     _assert_all([("poisson", e0), (2, e2)], name=f"{case}_full_size_vs_oracle")
+
+
+@pytest.mark.parametrize("nslabs", [1, 3])
+def test_asymmetric_physics_vs_oracle(pkg, O, nslabs):
+    """voltage != voltage2 and every physics knob off its default (the G8 parameter set), ragged grid,
+    one context and three uneven slabs: a plate swap or a K/Kn, diffu/diffun mix-up would show."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", golden_path("make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    po = O.default_params(70, 5, 40)
+    po.pb_iterations = 25
+    for k, v in mg.ASYM.items():
+        setattr(po, k, v)
+    if nslabs == 1:
+        _assert_all(_run_pair(pkg, O, po, [1, 4, 12]), name="asymmetric_physics")
+        return
+    orc = O.Oracle(po)
+    orc.initialization()
+    start = O.perturb_fields(po, orc.fields())
+    orc.set_fields(start); orc.fast_poisson(); orc.init_equilibrium(); orc.step(8)
+    with pkg.Group(_mirror(pkg, po), nslabs, devices=[0] * nslabs) as g:
+        g.initialization()
+        g.set_fields(start); g.fast_Poisson(); g.init_equilibrium(); g.step(8)
+        _assert_all([(8, O.rel_l2(g.fields(), orc.fields()))], name="asymmetric_physics_slabs")
+        assert abs(g.current() - orc.current()) <= 1e-8 * abs(orc.current())

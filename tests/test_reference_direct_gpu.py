@@ -203,3 +203,56 @@ def test_extra_grid_G5_poisson_and_first_step_moments(pkg, O, grid):
     err = O.rel_l2(f, {k: g["g2_step1_" + k] for k in f}, {k: [k] for k in f})
     _REPORT.append({"test": f"G2_step1_moments[{grid}]", "mark": "1", "rel_l2": err})
     assert max(err.values()) < 1e-13, err
+
+
+@pytest.mark.parametrize("grid", ["50x8x51", "130x6x19"])
+def test_asymmetric_physics_G8_hip_vs_reference_direct(pkg, O, grid):
+    """G8: the two plates at different zeta potentials and every physics knob off its default (the
+    reference's symbols written at run time).  Both runs - the x-y uniform one from initialization()
+    and the perturbed 3-D one - through the public C ABI with the reference's DC constants injected."""
+    g = _need(f"ref_{grid}_g8.npz")
+    nx, ny, nz = (int(v) for v in g["grid"])
+    p = pkg.default_params(nx, ny, nz)
+    if grid == "50x8x51":
+        p.Lx, p.Ly, p.Lz = 0.5e-6, 0.08e-6, 0.5e-6
+    for k, v in zip(g["param_names"], g["param_values"]):
+        setattr(p, str(k), float(v))
+    assert p.voltage != p.voltage2
+    name = f"G8_direct[{grid}]"
+    col = lambda d: {k: v[:, 0, 0] for k, v in d.items()}  # noqa: E731
+    with pkg.Solver(p) as s:
+        s.call("init_fields")
+        s.call("pbe_begin")
+        for sh in g["a1_init_shifts"]:
+            s.call("pbe_concentrations")
+            s.fast_Poisson()
+            inject_leak(s, p, float(sh))
+            s.call("pbe_relax")
+        s.call("pbe_end")
+        _check(O, name, "init", col(s.fields()), {k: g["a1_init_" + k] for k in O.FIELDS}, {k: v for k, v in O.GROUPS.items() if k != "u"})
+        s.init_equilibrium()
+        done = 0
+        for mark in (int(m) for m in g["a1_marks"]):
+            for k in range(done, mark):
+                s.stream_collide_save()
+                s.fast_Poisson()
+                inject_leak(s, p, float(g["a1_step_shifts"][k]))
+            done = mark
+            _check(O, name, f"uniform {mark}", col(s.fields()), {k: g[f"a1_step{mark}_{k}"] for k in O.FIELDS})
+    ys = list(g["ysel"])
+    sub = lambda d: {k: v[:, ys, :] for k, v in d.items()}  # noqa: E731
+    with pkg.Solver(p) as s:
+        s.call("init_fields")
+        s.set_fields({k: g["a2_input_" + k] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+        s.fast_Poisson()
+        inject_leak(s, p, float(g["a2_shifts"][0]))
+        _check(O, name, "perturbed 0", sub(s.fields()), {k: g["a2_step0_" + k] for k in O.FIELDS}, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
+        s.init_equilibrium()
+        done = 0
+        for mark in (int(m) for m in g["a2_marks"]):
+            for k in range(done, mark):
+                s.stream_collide_save()
+                s.fast_Poisson()
+                inject_leak(s, p, float(g["a2_shifts"][1 + k]))
+            done = mark
+            _check(O, name, f"perturbed {mark}", sub(s.fields()), {k: g[f"a2_step{mark}_{k}"] for k in O.FIELDS})

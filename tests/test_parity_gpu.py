@@ -101,9 +101,11 @@ def test_reference_default_grid_full_init_20_steps(pkg, O):
     assert res[-1][1]["u"] < 1e-6
 
 
-@pytest.mark.parametrize("shape", [(80, 6, 9), (130, 4, 8), (64, 3, 6), (1, 1, 5), (7, 5, 4)])
+@pytest.mark.parametrize("shape", [(80, 6, 9), (130, 4, 8), (64, 3, 6), (1, 1, 5), (7, 5, 4), (20, 4, 66), (20, 4, 67), (128, 2, 5)])
 def test_ragged_and_tiny_grids(pkg, O, shape):
-    """nx not a multiple of the 64-lane wave, nx > 64 with a partial last segment, nx == 1."""
+    """nx not a multiple of the 64-lane wave, nx > 64 with a partial last segment, nx == 1, the last
+    channel height the cyclic-reduction z solve takes (66 planes) and the first one the serial
+    sweep takes (67), rows of exactly two tiles."""
     po = O.default_params(*shape)
     po.pb_iterations = 10
     _assert_all(_run_pair(pkg, O, po, [1, 3]))
@@ -455,7 +457,7 @@ def test_graph_replay_is_bitwise_the_eager_path(pkg, O, monkeypatch):
     assert abs(outs[0][1] - 26 * p.dt) < 1e-22
 
 
-@pytest.mark.parametrize("shape", [(24, 6, 150), (16, 12, 17), (70, 3, 66)])
+@pytest.mark.parametrize("shape", [(24, 6, 150), (16, 12, 17), (70, 3, 66), (7, 5, 4), (9, 3, 5)])
 def test_in_place_mode_is_bitwise_the_two_buffer_mode(pkg, O, shape):
     """in_place = 1: one population buffer, every sweep writes the lattice 65 planes further down /
     up (bulk launches of 64 planes in z order).  Same kernels, same arithmetic per node: the
@@ -662,3 +664,14 @@ def test_asymmetric_physics_vs_oracle(pkg, O, nslabs):
         g.set_fields(start); g.fast_Poisson(); g.init_equilibrium(); g.step(8)
         _assert_all([(8, O.rel_l2(g.fields(), orc.fields()))], name="asymmetric_physics_slabs")
         assert abs(g.current() - orc.current()) <= 1e-8 * abs(orc.current())
+
+
+def test_anisotropic_spacings_vs_oracle(pkg, O):
+    """dx != dy != dz and a box that is not NX dx long: the Poisson solve takes kx, ky from Lx, Ly
+    (main.cu:119-136), its z operator from dz (poisson.cu:176) and E from dx, dy, dz
+    (poisson.cu:53-55) separately; every other test has dx = dy = dz = 1e-8 and L = N d."""
+    po = O.default_params(40, 12, 21)
+    po.pb_iterations = 15
+    po.dy, po.dz = 1.7e-8, 0.8e-8
+    po.Lx, po.Ly, po.Lz = 40 * 1.0e-8 * 1.3, 12 * 1.7e-8, 20 * 0.8e-8
+    _assert_all(_run_pair(pkg, O, po, [1, 6]), name="anisotropic_spacings")

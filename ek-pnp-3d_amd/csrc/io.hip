@@ -177,14 +177,15 @@ int read_part_turn(Ctx& c, void* arg) {
   ReadTurn* a = static_cast<ReadTurn*>(arg);
   return io_read_data_part(c, a->path, a->time);
 }
-const char* const kNoTransport = "file IO on a slab context without a transport: attach one (ekpnp_slab_attach_comm) or use ekpnp_group_*";
+const char* const kNoTransport = "whole-lattice file IO on a slab context without a transport of its own: attach one (ekpnp_slab_attach_comm) or use ekpnp_group_*";
 }  // namespace
 
 extern "C" int ekpnp_save_data_tecplot(ekpnp_ctx* ctx, const char* path, int append, double time, int first) {
   NEEDCTX(ctx);
   if (!path) return fail(c, "NULL path");
   TextIoArgs a{path, append, time, first, 0};
-  if (c.slab && c.nranks > 1) return c.team ? team_ctx_turns(c, write_part_turn, &a) : fail(c, kNoTransport);
+  if (c.team && !team_is_group(c)) return team_ctx_turns(c, write_part_turn, &a);  // the ranks take turns in z order
+  if (c.slab && c.nranks > 1) return fail(c, kNoTransport);
   return io_write_text_part(c, a);
 }
 
@@ -192,17 +193,19 @@ extern "C" int ekpnp_save_data_end(ekpnp_ctx* ctx, const char* path, int append,
   NEEDCTX(ctx);
   if (!path) return fail(c, "NULL path");
   TextIoArgs a{path, append, time, 0, 1};
-  if (c.slab && c.nranks > 1) return c.team ? team_ctx_turns(c, write_part_turn, &a) : fail(c, kNoTransport);
+  if (c.team && !team_is_group(c)) return team_ctx_turns(c, write_part_turn, &a);
+  if (c.slab && c.nranks > 1) return fail(c, kNoTransport);
   return io_write_text_part(c, a);
 }
 
 extern "C" int ekpnp_read_data(ekpnp_ctx* ctx, const char* path, double* time) {
   NEEDCTX(ctx);
   if (!path || !time) return fail(c, "NULL pointer");
-  if (c.slab && c.nranks > 1) {
+  if (c.team && !team_is_group(c)) {
     ReadTurn a{path, time};
-    return c.team ? team_ctx_turns(c, read_part_turn, &a) : fail(c, kNoTransport);
+    return team_ctx_turns(c, read_part_turn, &a);
   }
+  if (c.slab && c.nranks > 1) return fail(c, kNoTransport);
   return io_read_data_part(c, path, time);
 }
 

@@ -24,6 +24,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -557,7 +558,10 @@ extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
   if (!T) { c.err = "host allocation failed"; return EKPNP_ERR_NOMEM; }
   T->m = {ctx};
   T->nranks = c.nranks;
-  T->all_local = c.nranks == 1;
+  // one rank: everything is local and host-side combining would do; EKPNP_TEAM_FORCE_COLLECTIVES makes the
+  // reductions and the file-IO turns take the multi-process route anyway (ncclAllReduce over the one
+  // rank), so that those code paths can be exercised on a one-GPU box (tests/test_group_gpu.py)
+  T->all_local = c.nranks == 1 && std::getenv("EKPNP_TEAM_FORCE_COLLECTIVES") == nullptr;
   T->group = false;
   T->kind = EKPNP_TRANSPORT_RCCL;
   T->nc = nc;

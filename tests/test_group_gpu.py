@@ -391,3 +391,51 @@ def test_uneven_slabs_vs_oracle(pkg, O, shape, nslabs, in_place):
         assert ext[0][0] == 0 and ext[-1][0] + ext[-1][1] == shape[2]
         assert all(a[0] + a[1] == b[0] for a, b in zip(ext, ext[1:])) and max(e[1] for e in ext) - min(e[1] for e in ext) == 1
         _drive(O, g, po, ref, 6)
+
+
+def test_attached_slab_collectives_and_file_turns(pkg, O, tmp_path):
+    """The multi-process routes of an attached slab - ncclAllReduce for current / umax / the converged
+    start's residual, the rank-by-rank turns of the whole-lattice writers and of read_data - forced
+    on one rank (EKPNP_TEAM_FORCE_COLLECTIVES, read when the communicator is attached): results and
+    files must be the single-context ones."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as G
+pkg = G.load_package(); O = G.load_oracle()
+out = sys.argv[1]
+shape = (20, 6, 24)
+p = pkg.default_params(*shape); p.pb_iterations = 8
+po = O.default_params(*shape)
+def drive(s, tag):
+    n, res = s.initialization_converged(1e-9, 3000)
+    s.set_fields(O.perturb_fields(po, s.fields()))
+    s.fast_Poisson(); s.init_equilibrium(); s.step(5)
+    s.save_data_tecplot(f"{out}/{tag}.dat", 1e-9, first=True)
+    s.save_data_end(f"{out}/{tag}_end.dat", 1e-9)
+    s.record_umax(f"{out}/{tag}_umax.dat", 1e-9, append=False)
+    cur, um = s.current(), s.umax()
+    t = s.read_data(f"{out}/{tag}_end.dat")
+    return n, cur, um, s.fields()
+with pkg.Solver(p) as s:
+    a = drive(s, "one")
+s = pkg.Solver(p, 0, 1, slab=True)
+s.attach_comm(pkg.comm_unique_id())
+b = drive(s, "slab")
+s.close()
+assert a[0] == b[0], (a[0], b[0])
+assert abs(a[1] - b[1]) <= 1e-9 * abs(a[1]) and abs(a[2] - b[2]) <= 1e-6 * abs(a[2]) + 1e-30, (a[1:3], b[1:3])
+for k in a[3]:
+    assert np.array_equal(a[3][k], b[3][k]), k   # what read_data brought back (%%10.6f text) is identical
+print("OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EKPNP_TEAM_FORCE_COLLECTIVES="1")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    for name in ("umax.dat",):
+        assert (tmp_path / f"one_{name}").read_bytes() == (tmp_path / f"slab_{name}").read_bytes()
+    a, b = np.loadtxt(tmp_path / "one_end.dat"), np.loadtxt(tmp_path / "slab_end.dat")
+    assert a.shape == b.shape and np.abs(a - b).max() <= 2e-6

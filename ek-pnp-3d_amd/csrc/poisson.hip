@@ -729,7 +729,7 @@ void launch_phi_efield(Ctx& c) {
 #define EKPNP_PHI_X2_THREADS 256  // A/B knob
 #endif
     const int bx = c.p.nx >= 2 * EKPNP_PHI_X2_THREADS ? EKPNP_PHI_X2_THREADS : c.p.nx / 2;  // threads per block, each two nodes
-    const int nxb = c.p.nx / (2 * bx);
+    const int nxb = (c.p.nx + 2 * bx - 1) / (2 * bx);  // the last block of a row may be partly idle (whole waves: nx % 128 == 0)
     hipLaunchKernelGGL(k_phi_efield_x2<PHI_ZCHUNK_LARGE>, dim3((unsigned)(8 * per_xcd * nxb)), dim3(bx), 0, c.stream, a, nxb, nrows);
     note_launch(c, "k_phi_efield_x2<PHI_ZCHUNK_LARGE>");
     return;

@@ -576,6 +576,15 @@ def test_bench_start_profile_from_the_product_vs_gouy_chapman(pkg):
     assert abs(prof["phi"][256]) < 1e-7  # the double layers do not reach the mid-plane (2 zeta exp(-128/9.2) ~ 1e-8)
 
 
+@pytest.mark.parametrize("shape", [(640, 64, 52), (384, 96, 58), (1152, 32, 58)])
+def test_large_lattice_row_lengths_vs_oracle(pkg, O, shape):
+    """Rows that are a multiple of 128 but not of 512 nodes (640 = 512 + 128, 384, 1152): the
+    two-nodes-per-lane phi/E kernel with a partly idle last workgroup per row, 2.1 M nodes each."""
+    po = O.default_params(*shape)
+    po.pb_iterations = 3
+    _assert_all(_run_pair(pkg, O, po, [1, 2]), name=f"large_rows_{shape[0]}")
+
+
 @pytest.mark.parametrize("nz,nslabs", [(130, 1), (258, 2)])
 def test_large_lattice_kernels_vs_oracle(pkg, O, nz, nslabs):
     """The kernels only large lattices use - the two-nodes-per-lane phi/E kernel (rows of a multiple

@@ -576,22 +576,25 @@ def test_bench_start_profile_from_the_product_vs_gouy_chapman(pkg):
     assert abs(prof["phi"][256]) < 1e-7  # the double layers do not reach the mid-plane (2 zeta exp(-128/9.2) ~ 1e-8)
 
 
-@pytest.mark.parametrize("shape", [(640, 64, 52), (384, 96, 58), (1152, 32, 58)])
+@pytest.mark.parametrize("shape", [(640, 64, 52), (384, 96, 58), (1152, 32, 58), (200, 100, 110), (65, 200, 170), (1000, 30, 71), (130, 129, 127),
+                                   (255, 97, 87), (2050, 12, 87)])
 def test_large_lattice_row_lengths_vs_oracle(pkg, O, shape):
-    """Rows that are a multiple of 128 but not of 512 nodes (640 = 512 + 128, 384, 1152): the
-    two-nodes-per-lane phi/E kernel with a partly idle last workgroup per row, 2.1 M nodes each."""
+    """>= 2 M nodes (the large-lattice launch shapes: 16-plane marching, serial z solve) with rows
+    that are a multiple of 128 but not of 512 nodes (640 = 512 + 128, 384, 1152: the two-nodes-per-lane
+    phi/E kernel with a partly idle last workgroup per row) and rows that are no multiple of 128 at
+    all (the one-node-per-lane kernel: 200, 65, 1000, 130, 255, 2050 nodes; odd ny, odd nz)."""
     po = O.default_params(*shape)
     po.pb_iterations = 3
     _assert_all(_run_pair(pkg, O, po, [1, 2]), name=f"large_rows_{shape[0]}")
 
 
-@pytest.mark.parametrize("nz,nslabs", [(130, 1), (258, 2)])
-def test_large_lattice_kernels_vs_oracle(pkg, O, nz, nslabs):
+@pytest.mark.parametrize("shape,nslabs", [((128, 128, 130), 1), ((128, 128, 258), 2), ((128, 128, 259), 2), ((200, 100, 221), 2)])
+def test_large_lattice_kernels_vs_oracle(pkg, O, shape, nslabs):
     """The kernels only large lattices use - the two-nodes-per-lane phi/E kernel (rows of a multiple
-    of 128 nodes, >= 2 M nodes per context), 16-plane marching, the serial Thomas z solve - against
-    the oracle: 128x128x130 in one context, 128x128x258 in two slabs (the same kernels with the phi
-    halo planes and the distributed z solve)."""
-    po = O.default_params(128, 128, nz)
+    of 128 nodes, >= 2 M nodes per context) or its one-node-per-lane sibling (200-node rows), 16-plane
+    marching, the serial Thomas z solve - against the oracle: one context, and two slabs (even and
+    uneven) where the same kernels see the phi halo planes and the distributed z solve."""
+    po = O.default_params(*shape)
     po.pb_iterations = 3
     orc = O.Oracle(po)
     orc.initialization()
@@ -608,7 +611,7 @@ def test_large_lattice_kernels_vs_oracle(pkg, O, nz, nslabs):
         e0 = O.rel_l2(s.fields(), pois, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
         s.init_equilibrium(); s.step(3)
         e3 = O.rel_l2(s.fields(), want)
-    _assert_all([("poisson", e0), (3, e3)], name=f"large_lattice_{nz}_{nslabs}")
+    _assert_all([("poisson", e0), (3, e3)], name=f"large_lattice_{shape[0]}x{shape[2]}_{nslabs}")
 
 
 @pytest.mark.parametrize("case", ["cfg2", "cfg3_width"])

@@ -588,8 +588,9 @@ def test_large_lattice_row_lengths_vs_oracle(pkg, O, shape):
     _assert_all(_run_pair(pkg, O, po, [1, 2]), name=f"large_rows_{shape[0]}")
 
 
-@pytest.mark.parametrize("shape,nslabs", [((128, 128, 130), 1), ((128, 128, 258), 2), ((128, 128, 259), 2), ((200, 100, 221), 2)])
-def test_large_lattice_kernels_vs_oracle(pkg, O, shape, nslabs):
+@pytest.mark.parametrize("shape,nslabs,in_place", [((128, 128, 130), 1, 0), ((128, 128, 258), 2, 0), ((128, 128, 259), 2, 0), ((200, 100, 221), 2, 0),
+                                                   ((128, 128, 130), 1, 1), ((128, 128, 259), 2, 1)])
+def test_large_lattice_kernels_vs_oracle(pkg, O, shape, nslabs, in_place):
     """The kernels only large lattices use - the two-nodes-per-lane phi/E kernel (rows of a multiple
     of 128 nodes, >= 2 M nodes per context) or its one-node-per-lane sibling (200-node rows), 16-plane
     marching, the serial Thomas z solve - against the oracle: one context, and two slabs (even and
@@ -605,13 +606,14 @@ def test_large_lattice_kernels_vs_oracle(pkg, O, shape, nslabs):
     want = orc.fields()
     orc.close()
     p = _mirror(pkg, po)
+    p.in_place = in_place
     with (pkg.Solver(p) if nslabs == 1 else pkg.Group(p, nslabs, devices=[0] * nslabs)) as s:
         s.initialization()
         s.set_fields(start); s.fast_Poisson()
         e0 = O.rel_l2(s.fields(), pois, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
         s.init_equilibrium(); s.step(3)
         e3 = O.rel_l2(s.fields(), want)
-    _assert_all([("poisson", e0), (3, e3)], name=f"large_lattice_{shape[0]}x{shape[2]}_{nslabs}")
+    _assert_all([("poisson", e0), (3, e3)], name=f"large_lattice_{shape[0]}x{shape[2]}_{nslabs}_{in_place}")
 
 
 @pytest.mark.parametrize("case", ["cfg2", "cfg3_width"])

@@ -254,12 +254,27 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.shift = c.inplace ? c.zchunk + 1 : 0;
   const size_t popbytes = (size_t)(c.nzl + 2 + c.shift) * c.pplane * sizeof(double);
   // (skewing the population arrays against each other like the macroscopic arrays below was
-  // measured too: -1.5 %, profiles/r01_sweep_skew.log - they stay where hipMalloc puts them)
-  for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
-    for (int l = 0; l < p->n_lattices; ++l) {
-      if ((rc = dev_alloc(c, &c.pop_alloc[b][l], popbytes))) return bail(rc);
-      c.pop[b][l] = (double*)c.pop_alloc[b][l];
-    }
+  // measured in round 1: -1.5 %, profiles/r01_sweep_skew.log)
+  // All population buffers are carved out of ONE allocation.  With a hipMalloc per buffer (8 of 29 GB on
+  // cfg3) the step time of otherwise identical contexts spread over 42.5 ... 44.2 ms depending on where
+  // the driver happened to place them; out of one 233 GB allocation it is 42.5 ... 42.7 ms, every time
+  // (profiles/r02_population_arena.log).  EKPNP_POP_ARENA=<bytes> puts a gap between the buffers (0 and
+  // 4096 measured the same), EKPNP_POP_ARENA=-1 restores one allocation per buffer (the A/B partner).
+  static const long long arena_gap = std::getenv("EKPNP_POP_ARENA") ? std::atoll(std::getenv("EKPNP_POP_ARENA")) : 0;
+  if (arena_gap >= 0) {
+    const int nbuf = (c.inplace ? 1 : 2) * p->n_lattices;
+    const size_t pitch = (popbytes + (size_t)arena_gap + 255) / 256 * 256;
+    if ((rc = dev_alloc(c, &c.pop_alloc[0][0], pitch * nbuf))) return bail(rc);
+    int k = 0;
+    for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
+      for (int l = 0; l < p->n_lattices; ++l, ++k) c.pop[b][l] = (double*)((char*)c.pop_alloc[0][0] + pitch * k);
+  } else {
+    for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
+      for (int l = 0; l < p->n_lattices; ++l) {
+        if ((rc = dev_alloc(c, &c.pop_alloc[b][l], popbytes))) return bail(rc);
+        c.pop[b][l] = (double*)c.pop_alloc[b][l];
+      }
+  }
   if (c.inplace && slab)
     for (int l = 0; l < p->n_lattices; ++l)
       if ((rc = dev_alloc(c, (void**)&c.stage[l], 2 * c.pplane * sizeof(double)))) return bail(rc);
@@ -268,6 +283,17 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   // their streams queue on the same channels.  Each owned array is therefore skewed by a different
   // multiple of `skew` bytes inside a slightly larger allocation (EKPNP_FIELD_SKEW: tuning knob).
   static const size_t skew = std::getenv("EKPNP_FIELD_SKEW") ? (size_t)std::atoll(std::getenv("EKPNP_FIELD_SKEW")) : 4096;
+  // EKPNP_FIELD_ARENA=1 (tuning experiment): the 11 arrays out of one allocation, same skew
+  static const bool field_arena = std::getenv("EKPNP_FIELD_ARENA") != nullptr && std::atoi(std::getenv("EKPNP_FIELD_ARENA")) != 0;
+  if (field_arena) {
+    const size_t pitch = (c.nloc * sizeof(double) + (size_t)EKPNP_NFIELDS * skew + 255) / 256 * 256;
+    if ((rc = dev_alloc(c, &c.fld_arena, pitch * EKPNP_NFIELDS))) return bail(rc);
+    for (int i = 0; i < EKPNP_NFIELDS; ++i) {
+      c.fld[i] = (double*)((char*)c.fld_arena + pitch * i + (size_t)i * skew);
+      c.fld_owned[i] = true;
+      if (hipMemsetAsync(c.fld[i], 0, c.nloc * sizeof(double), c.stream) != hipSuccess) { c.err = "hipMemsetAsync failed"; return bail(EKPNP_ERR_HIP); }
+    }
+  } else
   for (int i = 0; i < EKPNP_NFIELDS; ++i) {
     c.fld_bytes[i] = c.nloc * sizeof(double) + (size_t)EKPNP_NFIELDS * skew;
     if ((rc = dev_alloc(c, &c.fld_alloc[i], c.fld_bytes[i]))) { c.fld_bytes[i] = 0; return bail(rc); }
@@ -356,6 +382,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
     if (c.stage[l]) (void)hipFree(c.stage[l]);
   for (int i = 0; i < EKPNP_NFIELDS; ++i)
     if (c.fld_alloc[i] && c.fld_owned[i]) (void)hipFree(c.fld_alloc[i]);
+  if (c.fld_arena) (void)hipFree(c.fld_arena);
   if (c.work) (void)hipFree(c.work);
   if (c.spec) (void)hipFree(c.spec);
   if (c.cprime) (void)hipFree(c.cprime);
@@ -407,7 +434,7 @@ extern "C" int ekpnp_bind_field(ekpnp_ctx* ctx, int id, double* dptr) {
   HIPCHK(c, hipStreamSynchronize(c.stream));
   HIPCHK(c, hipMemcpy(dptr, c.fld[id], c.nloc * sizeof(double), hipMemcpyDeviceToDevice));
   if (c.fld_owned[id]) {
-    (void)hipFree(c.fld_alloc[id]);
+    if (c.fld_alloc[id]) (void)hipFree(c.fld_alloc[id]);  // (an array inside a shared arena stays allocated until ekpnp_destroy)
     c.fld_alloc[id] = nullptr;
     c.bytes -= c.fld_bytes[id];  // the whole allocation, skew pad included
     c.fld_bytes[id] = 0;

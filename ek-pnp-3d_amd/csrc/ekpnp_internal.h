@@ -163,7 +163,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   double* pop[2][MAXL] = {};   // [buffer][lattice]; in-place mode uses pop[0] only
-  void* pop_alloc[2][MAXL] = {};  // what hipMalloc returned (pop[b][l] is skewed into it)
+  void* pop_alloc[2][MAXL] = {};  // what hipMalloc returned: [0][0] alone when all buffers share one allocation (default)
   int cur = 0;                 // A/B mode: buffer holding the current state.  In-place mode: the
                                // parity of the storage offset (0: lattice at +shift planes, the
                                // next sweep runs z-ascending and writes at offset 0; 1: mirror)
@@ -187,6 +187,7 @@ struct Ctx {
   bool fld_owned[EKPNP_NFIELDS] = {};
   void* fld_alloc[EKPNP_NFIELDS] = {};  // what hipMalloc returned for an owned field (fld[i] is skewed into it)
   size_t fld_bytes[EKPNP_NFIELDS] = {}; // size of that allocation (skew pad included)
+  void* fld_arena = nullptr;            // EKPNP_FIELD_ARENA: the owned fields share this one allocation
   double* work = nullptr;
   double2* spec = nullptr;
   // the transforms run over the owned interior planes [fft_z0, fft_z0 + fft_nz): right-hand side in

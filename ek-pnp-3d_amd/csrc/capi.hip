@@ -757,8 +757,10 @@ extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
   NEEDCTX(ctx);
   (void)t;  // the reference passes t but never uses it (LBM.cu:483-1846)
   if (c.slab) return c.team ? team_ctx_stream_collide_save(c) : fail(c, "slab context without a transport: attach one, use ekpnp_group_*, or drive ekpnp_collide_boundary_planes/interior_planes + the halo exchange yourself");
-  // (running the two wall planes on a second stream beside the bulk kernel was measured: no gain,
-  // the bulk kernel already saturates HBM and merely stretches - profiles/r01_bench_after_tuning.log)
+  // (running the two wall planes on a second stream beside the bulk kernel was measured: no gain on
+  // large lattices, the bulk kernel already saturates HBM and merely stretches -
+  // profiles/r01_bench_after_tuning.log; on the launch-bound 50x8x51 lattice the fork / join events
+  // cost more than the overlap saves: 0.0505 vs 0.0388 ms/step, profiles/r02_small_grid_timing.log)
   const int zb = bulk_begin(c), ze = bulk_end(c);
   if (!c.inplace) {
     int rc = collide_range(c, zb, ze, true);

@@ -78,11 +78,14 @@ hipError_t take_launch_error(Ctx& c) {
 }
 }  // namespace ekpnp
 
+static void drop_graph(Ctx& c);
+
 // measurement hook (tools/sweep_zchunk.py): change a launch-shape knob of a live context
 extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
   if (!ctx || !knob) return EKPNP_ERR_INVALID;
   Ctx& c = ctx->c;
   if (std::strcmp(knob, "ab_zchunk") == 0 && value >= 0) { c.ab_zchunk = value; return EKPNP_OK; }
+  if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   c.err = "ekpnp_tune: unknown knob or bad value";
   return EKPNP_ERR_INVALID;
 }
@@ -245,6 +248,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.own_stream = true;
   if (hipGetDevice(&c.device) != hipSuccess) { c.err = "hipGetDevice failed"; return bail(EKPNP_ERR_HIP); }
   if (const char* e = std::getenv("EKPNP_BULK_ZCHUNK")) c.ab_zchunk = std::atoi(e) > 0 ? std::atoi(e) : 0;
+  c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
   // In-place mode: one buffer per lattice with `shift` spare planes.  A sweep writes plane z of
   // the new state `shift` planes below (parity 0, bulk launches of `zchunk` planes in ascending z)
   // or above (parity 1, descending) where plane z of the old state lies; shift >= zchunk + 1
@@ -762,7 +766,12 @@ extern "C" int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t) {
   // profiles/r01_bench_after_tuning.log; on the launch-bound 50x8x51 lattice the fork / join events
   // cost more than the overlap saves: 0.0505 vs 0.0388 ms/step, profiles/r02_small_grid_timing.log)
   const int zb = bulk_begin(c), ze = bulk_end(c);
-  if (!c.inplace) {
+  // launch-bound lattices: plates and bulk in ONE launch (k_collide_all): one kernel of the dependent
+  // chain less (the reference's 50x8x51: 0.0388 -> see profiles/r02_small_grid_timing.log); large lattices
+  // keep the lean bulk kernel and a separate wall kernel
+  if (!c.inplace && c.merged_walls && !c.timing && c.nloc <= (size_t)4 * 1024 * 1024 && c.nzl > 2) {
+    launch_collide_all(c);
+  } else if (!c.inplace) {
     int rc = collide_range(c, zb, ze, true);
     if (rc) return rc;
     launch_collide_walls(c, c.stream, true, true);

@@ -126,6 +126,7 @@ void launch_init_fields(Ctx&);
 void launch_pbe(Ctx&);
 void launch_pbe_relax(Ctx&, double* phi_old, double omega);
 void launch_init_equilibrium(Ctx&);
+void launch_collide_all(Ctx&);  // launch-bound lattices: plates and bulk in ONE launch (single two-buffer context)
 void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
 void launch_collide_bulk(Ctx&, const KArgs&, int zl_begin, int zl_end);
 void launch_collide_walls(Ctx&, const KArgs&, hipStream_t stream, bool lower, bool upper);
@@ -171,6 +172,7 @@ struct Ctx {
   int shift = 0;               // planes the lattice moves per sweep in in-place mode (0 in A/B mode)
   int zchunk = 0;              // planes per bulk launch in in-place mode (shift >= zchunk + 1)
   int ab_zchunk = 0;           // two-buffer mode: planes per bulk launch of the sweep (0: one launch)
+  bool merged_walls = true;    // launch-bound two-buffer lattices: plates and bulk in one launch (k_collide_all)
   // base pointer of lattice l's CURRENT state (plane zg = 0 is the ghost plane below)
   double* cur_base(int l) const {
     if (!inplace) return pop[cur][l];

@@ -148,20 +148,10 @@ __device__ __forceinline__ void equilibrium(const KArgs& a, double m, double vx,
 #ifndef EKPNP_BULK_MIN_WAVES
 #define EKPNP_BULK_MIN_WAVES 1  // tuning knob: min waves per SIMD the register allocator must allow
 #endif
+// the work of one bulk workgroup: row `row` of the launch (y = row % ny, plane zl_begin + row / ny), x block xb
 template <int NL, bool PULL>
-__global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(const KArgs a, const int zl_begin, const int nrows, const int nxb, const int rchunk) {
+__device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, const int row, const int xb) {
   __shared__ double mom[7][64];
-  // XCD-aware placement.  Workgroups are dealt round-robin over the 8 XCDs (bid % 8 picks the
-  // XCD).  Each XCD is given runs of `rchunk` CONSECUTIVE x rows (and walks along x inside a row),
-  // so that every one of the 27+27 direction streams is sequential per XCD instead of a 1-in-8
-  // row comb.  Measured on cfg3 (512^3, 4 lattices): 45.0 ms with rows dealt one by one,
-  // 43.0 ms with runs of >= 8 rows (profiles/r01_sweep_map.log); 64 is used.
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int r = slot / nxb;
-  const int xb = slot - r * nxb;
-  const int row = ((r / rchunk) * 8 + xcd) * rchunk + r % rchunk;
-  if (row >= nrows) return;  // whole workgroup leaves together
   const int y = row % a.ny;
   const int zl = zl_begin + row / a.ny;
   const int zg = zl + 1;
@@ -250,6 +240,29 @@ __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(
   }
 }
 
+// row of the launch a workgroup works on (XCD-aware placement), or -1 when it is beyond the last row
+__device__ __forceinline__ int bulk_row_of_block(const int nrows, const int nxb, const int rchunk, int& xb) {
+  // XCD-aware placement.  Workgroups are dealt round-robin over the 8 XCDs (bid % 8 picks the
+  // XCD).  Each XCD is given runs of `rchunk` CONSECUTIVE x rows (and walks along x inside a row),
+  // so that every one of the 27+27 direction streams is sequential per XCD instead of a 1-in-8
+  // row comb.  Measured on cfg3 (512^3, 4 lattices): 45.0 ms with rows dealt one by one,
+  // 43.0 ms with runs of >= 8 rows (profiles/r01_sweep_map.log); 64 is used.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int r = slot / nxb;
+  xb = slot - r * nxb;
+  const int row = ((r / rchunk) * 8 + xcd) * rchunk + r % rchunk;
+  return row < nrows ? row : -1;
+}
+
+template <int NL, bool PULL>
+__global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(const KArgs a, const int zl_begin, const int nrows, const int nxb, const int rchunk) {
+  int xb;
+  const int row = bulk_row_of_block(nrows, nxb, rchunk, xb);
+  if (row < 0) return;  // whole workgroup leaves together
+  bulk_body<NL, PULL>(a, zl_begin, row, xb);
+}
+
 // ------------------------------------------------------------------------------------------
 // wall planes (global z = 0 and z = NZ-1): one thread per wall node, lattices in sequence.
 
@@ -289,14 +302,9 @@ __device__ __forceinline__ void wall_scalar_pops(const KArgs& a, int lat, const 
   }
 }
 
+// one wall node: plate `top` (0 lower, 1 upper), node (x, y); one thread, the lattices in sequence
 template <int NL, bool PULL>
-__global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int first_wall) {
-  // one launch covers the walls this context owns: blockIdx.z = 0 is wall `first_wall`
-  // (0 lower plate, 1 upper plate), blockIdx.z = 1 the upper plate
-  const int top = first_wall + (int)blockIdx.z;
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  const int y = blockIdx.y;
-  if (x >= a.nx) return;
+__device__ __forceinline__ void wall_body(const KArgs& a, const int top, const int x, const int y) {
   const int zl = top ? a.nzl - 1 : 0;
   const int zg = zl + 1;
   const double TH_wall = top ? 0.0 : a.TH;  // LBM.cu:2226-2229 vs 2357-2412
@@ -404,6 +412,35 @@ __global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int fi
       const double k = a.mob[lat];
       collide_scalar(a, g, ms[lat - 1], ux + k * Ex, uy + k * Ey, uz + k * Ez, a.wp[lat], a.wm[lat], store);
     });
+  }
+}
+
+template <int NL, bool PULL>
+__global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int first_wall) {
+  // one launch covers the walls this context owns: blockIdx.z = 0 is wall `first_wall`
+  // (0 lower plate, 1 upper plate), blockIdx.z = 1 the upper plate
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  if (x >= a.nx) return;
+  wall_body<NL, PULL>(a, first_wall + (int)blockIdx.z, x, (int)blockIdx.y);
+}
+
+// Launch-bound lattices (the reference's own 50x8x51: wall planes 12 us, bulk 10 us, both pure latency):
+// ONE launch for the whole lattice.  The rows beyond the bulk rows are the plates' rows; there the first
+// wave of the workgroup does the wall nodes and the other waves leave (the row, hence the branch, is
+// uniform over the workgroup, so the barrier of the bulk path is never reached by a part of a workgroup).
+template <int NL, bool PULL>
+__global__ void __launch_bounds__(64 * NL) k_collide_all(const KArgs a, const int zl_begin, const int nrows_bulk, const int nxb, const int rchunk) {
+  int xb;
+  const int row = bulk_row_of_block(nrows_bulk + 2 * a.ny, nxb, rchunk, xb);
+  if (row < 0) return;
+  if (row < nrows_bulk) {
+    bulk_body<NL, PULL>(a, zl_begin, row, xb);
+  } else {
+    if (threadIdx.x >= 64) return;
+    const int w = row - nrows_bulk;  // [0, ny): lower plate, [ny, 2 ny): upper plate
+    const int x = xb * 64 + (int)threadIdx.x;
+    if (x >= a.nx) return;
+    wall_body<NL, PULL>(a, w / a.ny, x, w % a.ny);
   }
 }
 
@@ -595,6 +632,29 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
   else
     hipLaunchKernelGGL((k_collide_bulk<NL, true>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
   note_launch(c, "k_collide_bulk");
+}
+
+template <int NL>
+static void all_dispatch(Ctx& c, const KArgs& a) {
+  const int nrows_bulk = (c.nzl - 2) * c.p.ny, nrows = nrows_bulk + 2 * c.p.ny;
+  const int nxb = (c.p.nx + 63) / 64, rchunk = 64;
+  const long long per_xcd = ((long long)nrows + 8LL * rchunk - 1) / (8LL * rchunk) * rchunk;
+  dim3 g((unsigned)(8 * per_xcd * nxb)), b(64 * NL);
+  if (c.streamed_state)
+    hipLaunchKernelGGL((k_collide_all<NL, false>), g, b, 0, c.stream, a, 1, nrows_bulk, nxb, rchunk);
+  else
+    hipLaunchKernelGGL((k_collide_all<NL, true>), g, b, 0, c.stream, a, 1, nrows_bulk, nxb, rchunk);
+  note_launch(c, "k_collide_all");
+}
+
+// the whole lattice of a single two-buffer context (both plates and everything in between) in one launch
+void launch_collide_all(Ctx& c) {
+  const KArgs a = c.kargs();
+  switch (c.p.n_lattices) {
+    case 1: all_dispatch<1>(c, a); break;
+    case 3: all_dispatch<3>(c, a); break;
+    default: all_dispatch<4>(c, a); break;
+  }
 }
 
 void launch_collide_bulk(Ctx& c, int zl_begin, int zl_end) { launch_collide_bulk(c, c.kargs(), zl_begin, zl_end); }

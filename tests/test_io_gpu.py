@@ -293,7 +293,9 @@ with pkg.Solver(p) as s:
 
     r = run({"EKPNP_INJECT_LAUNCH_FAILURE": "k_pbe_relax"}, tmp_path / "x.npy")
     assert r.returncode == 0 and "ERR" in r.stdout and "kernel k_pbe_relax" in r.stdout, (r.stdout, r.stderr[-2000:])
-    r = run({"EKPNP_INJECT_LAUNCH_FAILURE": "k_collide_bulk"}, tmp_path / "x.npy")
+    r = run({"EKPNP_INJECT_LAUNCH_FAILURE": "k_collide_all"}, tmp_path / "x.npy")  # small lattice: plates + bulk in one launch
+    assert "ERR" in r.stdout and "kernel k_collide_all" in r.stdout, (r.stdout, r.stderr[-2000:])
+    r = run({"EKPNP_INJECT_LAUNCH_FAILURE": "k_collide_bulk", "EKPNP_NO_MERGED_WALLS": "1"}, tmp_path / "x.npy")
     assert "ERR" in r.stdout and "kernel k_collide_bulk" in r.stdout, (r.stdout, r.stderr[-2000:])
     a = run({}, tmp_path / "a.npy")
     b = run({"EKPNP_DEBUG_SYNC": "1"}, tmp_path / "b.npy")
@@ -350,6 +352,7 @@ def test_checkpoint_continues_the_run_bit_for_bit(pkg, O, tmp_path, save_mode, l
     p.in_place = save_mode
     path = str(tmp_path / "ck.bin")
     with pkg.Solver(p) as s:
+        s.tune("merged_walls", 0)  # across buffer modes the plates must come from the same kernel (k_collide_wall)
         s.initialization()
         s.set_fields(O.perturb_fields(po, s.fields()))
         s.fast_Poisson(); s.init_equilibrium(); s.step(7)
@@ -359,6 +362,7 @@ def test_checkpoint_continues_the_run_bit_for_bit(pkg, O, tmp_path, save_mode, l
     q = pkg.default_params(*shape)
     q.in_place = load_mode
     with pkg.Solver(q) as s:
+        s.tune("merged_walls", 0)
         t = s.load_checkpoint(path)
         assert abs(t - 7 * p.dt) < 1e-22
         s.step(6)
@@ -368,11 +372,13 @@ def test_checkpoint_continues_the_run_bit_for_bit(pkg, O, tmp_path, save_mode, l
         assert np.array_equal(got[k], want[k]), k
     # a checkpoint taken right after init_equilibrium (no collide yet) continues as well
     with pkg.Solver(p) as s:
+        s.tune("merged_walls", 0)  # across buffer modes the plates must come from the same kernel (k_collide_wall)
         s.initialization(); s.init_equilibrium()
         s.save_checkpoint(path)
         s.step(3)
         want = s.fields()
     with pkg.Solver(q) as s:
+        s.tune("merged_walls", 0)
         s.load_checkpoint(path); s.step(3)
         got = s.fields()
     for k in want:

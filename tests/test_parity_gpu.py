@@ -461,7 +461,11 @@ def test_graph_replay_is_bitwise_the_eager_path(pkg, O, monkeypatch):
 def test_in_place_mode_is_bitwise_the_two_buffer_mode(pkg, O, shape):
     """in_place = 1: one population buffer, every sweep writes the lattice 65 planes further down /
     up (bulk launches of 64 planes in z order).  Same kernels, same arithmetic per node: the
-    results must be identical bit for bit, with about half the population memory."""
+    results must be identical bit for bit, with about half the population memory.  (The two-buffer
+    mode is run with its plates and bulk in separate launches like the in-place mode has to: on
+    launch-bound lattices it otherwise merges them into one kernel, k_collide_all, in which the
+    compiler schedules the wall-node arithmetic differently - 1 ulp in u on the plates, see
+    test_merged_wall_kernel_equals_separate_launches.)"""
     po = O.default_params(*shape)
     po.pb_iterations = 12
     outs, mem = [], []
@@ -469,6 +473,7 @@ def test_in_place_mode_is_bitwise_the_two_buffer_mode(pkg, O, shape):
         p = _mirror(pkg, po)
         p.in_place = mode
         with pkg.Solver(p) as s:
+            s.tune("merged_walls", 0)
             s.initialization()
             s.set_fields(O.perturb_fields(po, s.fields()))
             s.fast_Poisson(); s.init_equilibrium()
@@ -481,6 +486,35 @@ def test_in_place_mode_is_bitwise_the_two_buffer_mode(pkg, O, shape):
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
     assert mem[1] < mem[0]
+
+
+def test_merged_wall_kernel_equals_separate_launches(pkg, O):
+    """Lattices of up to 4 M nodes collide their plates and bulk in one launch (k_collide_all: one
+    kernel less in the dependent chain, 0.039 -> 0.030 ms per step on the reference's 50x8x51).  The
+    bulk nodes get the same bits as from k_collide_bulk; on the plates the compiler schedules the
+    wall-node arithmetic differently inside the bigger kernel, which shows as 1 ulp in u there."""
+    po = O.default_params(50, 8, 51)
+    po.pb_iterations = 20
+    outs = []
+    for merged in (1, 0):
+        with pkg.Solver(_mirror(pkg, po)) as s:
+            s.tune("merged_walls", merged)
+            s.initialization()
+            s.set_fields(O.perturb_fields(po, s.fields()))
+            s.fast_Poisson(); s.init_equilibrium()
+            s.stream_collide_save(); s.fast_Poisson()
+            first = s.fields()
+            s.step(20)
+            outs.append((first, s.fields()))
+    (a1, a), (b1, b) = outs
+    for k in a1:  # after ONE collide: everything but u on the two plates is identical
+        if k in ("ux", "uy", "uz"):
+            assert np.array_equal(a1[k][1:-1], b1[k][1:-1]), k
+            assert np.abs(a1[k] - b1[k]).max() <= 4e-16 * np.abs(b1[k]).max(), k
+        else:
+            assert np.array_equal(a1[k], b1[k]), k
+    err = O.rel_l2(a, b)
+    assert all(v < (1e-9 if k == "u" else 1e-13) for k, v in err.items()), err
 
 
 def test_in_place_mode_vs_oracle(pkg, O):

@@ -586,6 +586,13 @@ extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
 
 // ---- C ABI: one process, N slabs (ekpnp_main --gpus N) -------------------------------------------
 
+// a group call visits several devices; the caller gets its current device back
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct ekpnp_group {
   Team t;
 };
@@ -596,6 +603,8 @@ extern "C" const char* ekpnp_group_last_error(const ekpnp_group* g) { return g ?
 
 extern "C" int ekpnp_group_destroy(ekpnp_group* g) {
   if (!g) return EKPNP_ERR_INVALID;
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) prev = -1;
   Team& T = g->t;
   team_release(T);
   for (ekpnp_ctx* m : T.m) {
@@ -604,6 +613,7 @@ extern "C" int ekpnp_group_destroy(ekpnp_group* g) {
     (void)ekpnp_destroy(m);
   }
   delete g;
+  if (prev >= 0) (void)hipSetDevice(prev);
   return EKPNP_OK;
 }
 
@@ -643,8 +653,7 @@ extern "C" int ekpnp_group_create(const ekpnp_params* p, int nslabs, const int* 
     ekpnp_group_destroy(g);
     return code;
   };
-  int prev = 0;
-  (void)hipGetDevice(&prev);
+  DeviceGuard device_guard_;
   for (int i = 0; i < nslabs; ++i) {
     if (hipSetDevice(dev[i]) != hipSuccess) { T.err = "hipSetDevice failed"; return bail(EKPNP_ERR_HIP); }
     ekpnp_ctx* c = nullptr;
@@ -674,13 +683,13 @@ extern "C" int ekpnp_group_create(const ekpnp_params* p, int nslabs, const int* 
         }
       }
   }
-  (void)hipSetDevice(prev);
   *out = g;
   return EKPNP_OK;
 }
 
 #define NEEDGROUP(g)                    \
   if (!(g)) return EKPNP_ERR_INVALID;   \
+  DeviceGuard device_guard_;            \
   Team& T = (g)->t
 
 extern "C" int ekpnp_group_size(const ekpnp_group* g) { return g ? (int)g->t.m.size() : 0; }

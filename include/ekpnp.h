@@ -317,7 +317,10 @@ int ekpnp_group_destroy(ekpnp_group* g);
 const char* ekpnp_group_last_error(const ekpnp_group* g); /* g == NULL: of the last failing ekpnp_group_create */
 int ekpnp_group_size(const ekpnp_group* g);
 int ekpnp_group_transport(const ekpnp_group* g);          /* EKPNP_TRANSPORT_RCCL or _COPY */
-int ekpnp_group_context(ekpnp_group* g, int slab, ekpnp_ctx** ctx); /* borrowed: for ekpnp_local_extent, timing hooks ... */
+int ekpnp_group_context(ekpnp_group* g, int slab, ekpnp_ctx** ctx); /* borrowed: for ekpnp_local_extent, timing hooks ...; calls that
+                                                                      touch the device need hipSetDevice(devices[slab]) first.
+                                                                      The ekpnp_group_* calls themselves leave the caller's
+                                                                      current device as they found it. */
 size_t ekpnp_group_device_bytes(const ekpnp_group* g);
 int ekpnp_group_synchronize(ekpnp_group* g);
 int ekpnp_group_set_field(ekpnp_group* g, int field_id, const double* host);

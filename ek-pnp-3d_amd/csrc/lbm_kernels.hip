@@ -53,13 +53,23 @@ struct Force {
   double x, y, z;
 };
 
+// u = (sum c_i f_i / CFL + F dt/2) / rho, LBM.cu:639-644.  The fused multiply-add is written out: with
+// -ffp-contract=fast the compiler may fuse either product of "j*cflinv + F*hdt", and it chose differently
+// in different kernels (1 ulp in u on the plates between k_collide_wall and k_collide_all); an explicit fma
+// leaves it no choice, so a node gets the same bits from every launch shape.
+__device__ __forceinline__ double velocity(double rhoinv, double j, double cflinv, double F, double hdt) {
+  return rhoinv * fma(F, hdt, j * cflinv);
+}
+// the body force, LBM.cu:635-637, with its fused multiply-adds written out for the same reason
+
+
 // body force, LBM.cu:635-637
 __device__ __forceinline__ Force body_force(const KArgs& a, double c, double cn, double T, double Ex, double Ey, double Ez) {
   Force F;
   const double q = a.F * (c - cn);
-  F.x = q * (Ex + a.Ext) + a.exf;
+  F.x = fma(q, Ex + a.Ext, a.exf);
   F.y = q * Ey;
-  F.z = q * Ez + a.rho0 * T * a.Ra * a.nu * a.D;
+  F.z = fma(q, Ez, a.rho0 * T * a.Ra * a.nu * a.D);
   return F;
 }
 
@@ -206,9 +216,9 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
   const Force F = body_force(a, c, cn, T, Ex, Ey, Ez);
   const double rhoinv = 1.0 / rho;
   const double hdt = a.dt * 0.5;
-  const double ux = rhoinv * (jx * a.cflinv + F.x * hdt);  // LBM.cu:639-644
-  const double uy = rhoinv * (jy * a.cflinv + F.y * hdt);
-  const double uz = rhoinv * (jz * a.cflinv + F.z * hdt);
+  const double ux = velocity(rhoinv, jx, a.cflinv, F.x, hdt);  // LBM.cu:639-644
+  const double uy = velocity(rhoinv, jy, a.cflinv, F.y, hdt);
+  const double uz = velocity(rhoinv, jz, a.cflinv, F.z, hdt);
 
   double* __restrict__ dst = a.B[lat] + ((long long)zg * a.ny + y) * a.rowstride + xo[1];
   auto store = [&](auto ic, double v) {
@@ -363,14 +373,14 @@ __device__ __forceinline__ void wall_body(const KArgs& a, const int top, const i
       m1[2] = sum27(g);
     }
     const Force F1 = body_force(a, m1[0], m1[1], m1[2], E1x, E1y, E1z);
-    ux = -rhoinv * (j1x * a.cflinv + F1.x * hdt);
-    uy = -rhoinv * (j1y * a.cflinv + F1.y * hdt);
-    uz = -rhoinv * (j1z * a.cflinv + F1.z * hdt);
+    ux = -velocity(rhoinv, j1x, a.cflinv, F1.x, hdt);
+    uy = -velocity(rhoinv, j1y, a.cflinv, F1.y, hdt);
+    uz = -velocity(rhoinv, j1z, a.cflinv, F1.z, hdt);
   } else {
     const Force F = body_force(a, ms[0], ms[1], ms[2], Ex, Ey, Ez);
-    ux = rhoinv * (jx * a.cflinv + F.x * hdt);
-    uy = rhoinv * (jy * a.cflinv + F.y * hdt);
-    uz = rhoinv * (jz * a.cflinv + F.z * hdt);
+    ux = velocity(rhoinv, jx, a.cflinv, F.x, hdt);
+    uy = velocity(rhoinv, jy, a.cflinv, F.y, hdt);
+    uz = velocity(rhoinv, jz, a.cflinv, F.z, hdt);
   }
   a.fld[EKPNP_RHO][sidx] = rho;
   a.fld[EKPNP_UX][sidx] = ux;

@@ -236,7 +236,8 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
 /* Launch-shape knobs of a live context, for tuning sweeps (tools/sweep_zchunk.py).  "ab_zchunk":
  * planes per launch of the two-buffer collide sweep (0 = the whole sweep in one launch).
  * "merged_walls": 1 (default) = lattices of up to 4 M nodes collide plates and bulk in ONE launch,
- * 0 = always separate launches (what large lattices, in-place contexts and slabs do anyway). */
+ * 0 = always separate launches (what large lattices, in-place contexts and slabs do anyway); same
+ * results bit for bit. */
 int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value);
 /* Every kernel launch of the library is checked: a rejected launch makes the entry point return
  * EKPNP_ERR_HIP with the KERNEL's name in ekpnp_last_error.  With EKPNP_DEBUG_SYNC set in the

@@ -352,7 +352,6 @@ def test_checkpoint_continues_the_run_bit_for_bit(pkg, O, tmp_path, save_mode, l
     p.in_place = save_mode
     path = str(tmp_path / "ck.bin")
     with pkg.Solver(p) as s:
-        s.tune("merged_walls", 0)  # across buffer modes the plates must come from the same kernel (k_collide_wall)
         s.initialization()
         s.set_fields(O.perturb_fields(po, s.fields()))
         s.fast_Poisson(); s.init_equilibrium(); s.step(7)
@@ -362,7 +361,6 @@ def test_checkpoint_continues_the_run_bit_for_bit(pkg, O, tmp_path, save_mode, l
     q = pkg.default_params(*shape)
     q.in_place = load_mode
     with pkg.Solver(q) as s:
-        s.tune("merged_walls", 0)
         t = s.load_checkpoint(path)
         assert abs(t - 7 * p.dt) < 1e-22
         s.step(6)
@@ -372,13 +370,11 @@ def test_checkpoint_continues_the_run_bit_for_bit(pkg, O, tmp_path, save_mode, l
         assert np.array_equal(got[k], want[k]), k
     # a checkpoint taken right after init_equilibrium (no collide yet) continues as well
     with pkg.Solver(p) as s:
-        s.tune("merged_walls", 0)  # across buffer modes the plates must come from the same kernel (k_collide_wall)
         s.initialization(); s.init_equilibrium()
         s.save_checkpoint(path)
         s.step(3)
         want = s.fields()
     with pkg.Solver(q) as s:
-        s.tune("merged_walls", 0)
         s.load_checkpoint(path); s.step(3)
         got = s.fields()
     for k in want:

@@ -23,6 +23,7 @@
  *        ref_driver <outdir> kernels <in.bin> <tag>     -> G4: populations after init_equilibrium, one
  *            full step, then after each of gpu_collide_save / gpu_boundary / gpu_stream / gpu_bc_charge
  *        ref_driver <outdir> time <nsteps>              -> wall time of the reference's own step
+ *        ref_driver <outdir> time0 <nsteps>             -> the same from uniform fields (large grids)
  *        ref_driver <outdir> io <in.bin> <tag>          -> upload fields; the reference's own
  *            save_data_tecplot (2 zones), save_data_end, record_umax and current() on them
  *        --set name=value writes a __constant__/__device__ physics symbol of LBM.h at run time
@@ -326,9 +327,17 @@ int main(int argc, char** argv) {
     dump_pops(out + "/" + tag + "_stream.bin", 1);
     gpu_bc_charge<<<grid, threads>>>(h0_gpu, h1_gpu, h2_gpu, hn0_gpu, hn1_gpu, hn2_gpu, temp0_gpu, temp1_gpu, temp2_gpu);
     dump_pops(out + "/" + tag + "_bc_charge.bin", 1);
-  } else if (mode == "time" && args.size() >= 2) {
-    /* throughput of the reference's own step (main.cu:189-200, no IO) on this GPU */
+  } else if ((mode == "time" || mode == "time0") && args.size() >= 2) {
+    /* throughput of the reference's own step (main.cu:189-200, no IO) on this GPU.  "time0" starts from the
+     * uniform fields of gpu_initialization alone (LBM.cu:76) instead of the 501 PB sweeps: on large grids those
+     * cost 2 x 501 full-field PCIe copies, and the sweep diverges beyond ~180 planes anyway; the time of a step
+     * does not depend on the values */
     const int n = atoi(args[1].c_str());
+    if (mode == "time0") {
+      dim3 grid0(NX / nThreads, NY, NZ);
+      dim3 threads0(nThreads, 1, 1);
+      gpu_initialization<<<grid0, threads0>>>(rho_gpu, charge_gpu, chargen_gpu, phi_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
+    } else
     initialization(rho_gpu, charge_gpu, chargen_gpu, phi_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
     init_equilibrium(f0_gpu, f1_gpu, h0_gpu, h1_gpu, hn0_gpu, hn1_gpu, temp0_gpu, temp1_gpu, rho_gpu, charge_gpu, chargen_gpu, ux_gpu,
                      uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu);
@@ -337,7 +346,7 @@ int main(int argc, char** argv) {
                           rho_gpu, charge_gpu, chargen_gpu, ux_gpu, uy_gpu, uz_gpu, Ex_gpu, Ey_gpu, Ez_gpu, T_gpu, t, f0bc);
       fast_Poisson(charge_gpu, chargen_gpu, kx, ky, kz, plan);
     };
-    for (int i = 0; i < 20; ++i) step();
+    for (int i = 0; i < (mode == "time0" ? 3 : 20); ++i) step();
     checkCudaErrors(hipDeviceSynchronize());
     const double t0 = seconds_now();
     for (int i = 0; i < n; ++i) step();

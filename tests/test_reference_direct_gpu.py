@@ -69,15 +69,16 @@ def inject_leak(s, p, shift):
     s.set_field("Ez", ez)
 
 
-def _check(O, name, mark, got, want, groups=None):
+def _check(O, name, mark, got, want, groups=None, wall_fraction=0.10):
     """Every group as usual - except that the velocity group is taken over the planes z >= 1 and
     plane z = 0 of u is checked node by node.  Reason: the reference's z==0 thread reads node z=1's
     rest populations (LBM.cu:664-667) while the z=1 thread overwrites them in the same launch
     (LBM.cu:1711-1714).  The product implements the canonical outcome (pre-collision values,
     SURVEY.md 8(c)); in the reference's own run on 70x6x83 two 10-thread blocks (20 of 210 sampled
     wall nodes, step 2) saw a mix - tests/test_oracle_cpu.py proves node by node that those values
-    are one of the 8 possible outcomes.  Here: at most 10 % of the wall nodes may deviate, and by no
-    more than the race can explain (1e-4 of |u|; SURVEY measured <= 2.4e-6 rel-L2)."""
+    are one of the 8 possible outcomes.  Here: at most `wall_fraction` of the wall nodes may deviate (10 %
+    on the fixtures; on a live 15.7 M-node run of the reference's kernels the scheduling is anybody's
+    guess), and by no more than the race can explain (1e-4 of |u|; SURVEY measured <= 2.4e-6 rel-L2)."""
     groups = groups or O.GROUPS
     u = ("ux", "uy", "uz")
     cut = lambda d: {k: (v[1:] if k in u else v) for k, v in d.items()}  # noqa: E731
@@ -88,7 +89,7 @@ def _check(O, name, mark, got, want, groups=None):
         d0 = np.max([np.abs(got[k][0] - want[k][0]) for k in u], axis=0)
         off = d0 > TOL_U * scale
         rec["wall_plane_u"] = {"nodes": int(d0.size), "raced_in_reference": int(off.sum()), "max_rel_dev": float(d0.max() / scale) if scale > 0 else 0.0}
-        assert off.mean() <= 0.10 and (scale == 0 or d0.max() <= 1e-4 * scale), (name, mark, rec)
+        assert off.mean() <= wall_fraction and (scale == 0 or d0.max() <= 1e-4 * scale), (name, mark, rec)
     _REPORT.append(rec)
     bad = {k: v for k, v in err.items() if not v <= (TOL_U if k == "u" else TOL)}
     assert not bad, (name, mark, err)
@@ -256,3 +257,62 @@ def test_asymmetric_physics_G8_hip_vs_reference_direct(pkg, O, grid):
                 inject_leak(s, p, float(g["a2_shifts"][1 + k]))
             done = mark
             _check(O, name, f"perturbed {mark}", sub(s.fields()), {k: g[f"a2_step{mark}_{k}"] for k in O.FIELDS})
+
+
+def test_reference_kernels_live_at_cfg2_scale(pkg, O, tmp_path):
+    """The reference's own kernels RUN HERE, on a 15.7 M-node lattice (250x250x251 - cfg2's scale; NX must be
+    a multiple of the reference's 10-thread blocks), against the HIP path on the same input: one Poisson
+    solve and two full steps, all 11 fields.  Uses oracle/_ref/ref_driver_250x250x251 (the reference's
+    LBM.cu / poisson.cu built for gfx950 by `oracle/build_ref.sh 250x250x251`; it travels to the GPU box
+    like the library's own .so) - skipped when that binary is not there.  The reference's DC constant of
+    every solve is read off its own output (it must be ONE constant over the interior) and injected into
+    the HIP run through the public API, exactly as in the fixture-based tests above."""
+    import subprocess
+
+    import bench
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = os.path.join(root, "oracle", "_ref", "ref_driver_250x250x251")
+    if not os.path.exists(drv):
+        pytest.skip("oracle/_ref/ref_driver_250x250x251 not built (oracle/build_ref.sh 250x250x251)")
+    nx, ny, nz = 250, 250, 251
+    n = nx * ny * nz
+    p = pkg.default_params(nx, ny, nz)
+    name = "reference_live_250x250x251"
+
+    def read_bin(path):
+        a = np.fromfile(path, dtype=np.float64)
+        assert a.size == 11 * n, (path, a.size)
+        return {k: a[i * n:(i + 1) * n].reshape(nz, ny, nx) for i, k in enumerate(O.FIELDS)}
+
+    with pkg.Solver(p) as s:
+        prof, _ = bench.pb_profile_from_product(pkg, p)
+        bench.product_pb_state(s, p, prof)
+        bench.apply_perturbation(s, None, p)
+        start = s.fields()
+        inp = tmp_path / "in.bin"
+        with open(inp, "wb") as f:
+            for k in O.FIELDS:
+                f.write(np.ascontiguousarray(start[k]).tobytes())
+        r = subprocess.run([drv, str(tmp_path), "fields", str(inp), "L", "1", "2"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+        os.remove(inp)
+
+        def leak_of(ref_phi, hip_phi):
+            d = ref_phi[1:-1] - hip_phi[1:-1]
+            sh = float(d.mean())
+            assert np.abs(d - sh).max() <= 1e-15, ("the reference's phi minus the exact solve is not one constant", np.abs(d - sh).max())
+            return sh
+
+        s.fast_Poisson()
+        ref = read_bin(tmp_path / "L_step0.bin")
+        inject_leak(s, p, leak_of(ref["phi"], s.get_field("phi")))
+        _check(O, name, 0, {k: s.get_field(k) for k in ("phi", "Ex", "Ey", "Ez")}, ref, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
+        s.init_equilibrium()
+        for step in (1, 2):
+            s.stream_collide_save()
+            s.fast_Poisson()
+            ref = read_bin(tmp_path / f"L_step{step}.bin")
+            inject_leak(s, p, leak_of(ref["phi"], s.get_field("phi")))
+            _check(O, name, step, s.fields(), ref, wall_fraction=1.0)
+            os.remove(tmp_path / f"L_step{step}.bin")

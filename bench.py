@@ -298,7 +298,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 data path.  nccl: the library's own RCCL transport (ekpnp_slab_attach_comm).  gloo: the host-staged "
                          "python transport of slab.py, only to rehearse the multi-rank flow on a one-GPU box")
-    ap.add_argument("--single-device", action="store_true", help="rehearsal: put every rank on device 0 (needs --backend gloo for N>1)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a one-GPU box: put every rank on device 0.  With --backend nccl each rank tells RCCL it is a "
+                         "different host (NCCL_HOSTID), so the library's real communicator, ring and all-gather run between the "
+                         "processes over RCCL's socket transport - functional coverage of the N>1 path, not a bandwidth figure")
     ap.add_argument("--force-slab", action="store_true",
                     help="N=1 only: run the multi-rank code path (split calls, comm stream, RCCL exchanges, the ring closing on the same rank)")
     ap.add_argument("--dry-run", action="store_true", help="check the launch plumbing only: rendezvous, barrier, one JSON line; no GPU")
@@ -340,8 +343,13 @@ def main():
 
     if args.single_device:
         local_rank = 0
-    if world > 1 and args.backend == "nccl" and args.single_device:
-        raise SystemExit("bench.py: RCCL refuses two ranks on one device; rehearse with --backend gloo --single-device")
+    rehearsal = world > 1 and args.backend == "nccl" and args.single_device
+    if rehearsal:
+        # RCCL refuses two ranks of one host on one device; ranks that claim different hosts are
+        # connected through its network (socket, loopback) transport instead.  Set before librccl loads.
+        os.environ["NCCL_HOSTID"] = f"ekpnp-rehearsal-rank{rank}"
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     torch.cuda.set_device(local_rank)
     pkg = G.load_package()
 
@@ -394,6 +402,8 @@ def main():
         elif native:
             sol = runner = pkg.Solver(p, rank, world, slab=True)
             transport = "RCCL inside libekpnp.so (ncclSend/ncclRecv ring + ncclAllGather, high-priority comm stream)"
+            if rehearsal:
+                transport += " - REHEARSAL: all ranks share device 0, RCCL socket transport; not a bandwidth figure"
         else:
             from ek_pnp_3d_amd.slab import DistributedSlab  # noqa: WPS433
 

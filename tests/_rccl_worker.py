@@ -1,0 +1,72 @@
+"""Worker of tests/test_slab_gpu.py::test_native_rccl_ranks_sharing_one_gpu: one process per rank, the
+library's OWN transport (ekpnp_slab_attach_comm: ncclCommInitRank, send/recv ring, all-gather,
+all-reduce), all ranks on the one GPU of the test box.  RCCL refuses two ranks of one host on one
+device, so every rank claims to be a different host (NCCL_HOSTID) and RCCL connects them through its
+socket transport over loopback: the library's code path is exactly the multi-GPU one, only RCCL's
+wire differs.  torch.distributed (gloo) is the control plane that hands the id round, as in bench.py."""
+import os
+import sys
+
+import numpy as np
+
+RANK = int(os.environ["RANK"])
+os.environ["NCCL_HOSTID"] = f"ekpnp-test-rank{RANK}"  # before librccl is loaded
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    pkg = G.load_package()
+    out = os.environ["EKPNP_SLAB_OUT"]
+    nx, ny, nz = (int(v) for v in os.environ["EKPNP_SLAB_GRID"].split("x"))
+    p = pkg.default_params(nx, ny, nz)
+    p.pb_iterations = 12
+    p.in_place = int(os.environ.get("EKPNP_SLAB_IN_PLACE", "0"))
+    s = pkg.Solver(p, rank, world, slab=True)
+    ident = [pkg.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ident, src=0)
+    s.attach_comm(ident[0])  # collective; from here every verb of the context is the whole-lattice one
+    s.initialization()
+    start = np.load(os.path.join(out, "start.npz"))
+    for k in ("rho", "c", "cn", "T", "ux", "uy", "uz"):
+        s.set_field(k, start[k][s.z0 : s.z0 + s.nz_local])
+    s.fast_Poisson()
+    s.init_equilibrium()
+    s.step(6)
+    s.synchronize()
+    current, umax = s.current(), s.umax()  # all-reduce inside the library
+    fields = s.fields()
+    # whole-lattice files, written plane by plane in rank order by the ranks taking turns
+    s.save_data_end(os.path.join(out, "data_end.dat"), 0.25)
+    s.save_data_tecplot(os.path.join(out, "tec.dat"), 0.25)
+    ckpt = os.path.join(out, f"ckpt_rank{rank}.bin")  # per-rank, self-contained (ghost planes travel)
+    s.save_checkpoint(ckpt)
+    # bitwise continuation from the checkpoint, against simply continuing
+    s.step(3)
+    cont = s.fields()
+    t_ck = s.load_checkpoint(ckpt)
+    s.step(3)
+    again = s.fields()
+    same = all(np.array_equal(cont[k], again[k]) for k in cont)
+    # the reference's restart route (fields -> equilibrium), collective read of the whole-lattice file
+    t_read = s.read_data(os.path.join(out, "data_end.dat"))
+    reread = s.fields()
+    np.savez(os.path.join(out, f"rank{rank}.npz"), z0=s.z0, current=current, umax=umax, ckpt_same=same, t_ck=t_ck, t_read=t_read,
+             **fields, **{"re_" + k: v for k, v in reread.items()})
+    dist.barrier()
+    s.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,13 @@ import os
 import sys
 
 import numpy as np
+
+if os.environ.get("EKPNP_SLAB_BACKEND", "gloo") == "nccl" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # several RCCL ranks on ONE device: each claims its own host, RCCL wires them over its socket transport
+    os.environ["NCCL_HOSTID"] = "ekpnp-test-rank" + os.environ["RANK"]
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
 import torch
 import torch.distributed as dist
 

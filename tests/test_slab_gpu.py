@@ -109,13 +109,14 @@ def _free_port():
 
 @pytest.mark.parametrize("shape,nprocs,in_place,backend", [((16, 12, 16), 2, 0, "gloo"), ((48, 20, 48), 4, 0, "gloo"),
                                                           ((24, 8, 48), 2, 1, "gloo"), ((32, 16, 40), 1, 0, "nccl"),
-                                                          ((32, 16, 40), 1, 1, "nccl")])
+                                                          ((32, 16, 40), 1, 1, "nccl"), ((24, 8, 36), 3, 0, "nccl")])
 def test_processes_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_place, backend):
     """The real multi-process path (DistributedSlab + RingTransport), launched like the driver
     launches bench.py: 2 and 4 ranks sharing the one GPU of the box over gloo (host-staged), and
     ONE rank over RCCL ("nccl"): a single slab whose ring neighbours are itself, so every halo,
     all-gather and phi exchange of the multi-GPU step really goes through RCCL send/recv on
-    tensors aliasing the library's device buffers (RCCL refuses two ranks on one device)."""
+    tensors aliasing the library's device buffers; and THREE ranks over RCCL, each claiming its own
+    host id so that RCCL accepts them on one device (socket transport; see _slab_worker.py)."""
     p = pkg.default_params(*shape)
     p.pb_iterations = 12
     po = O.default_params(*shape)
@@ -137,3 +138,57 @@ def test_processes_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_place, ba
     for d in parts:  # every rank holds the combined diagnostics
         assert abs(float(d["current"]) - want_current) <= 1e-9 * abs(want_current)
         assert abs(float(d["umax"]) - want_umax) <= 1e-6 * abs(want_umax) + 1e-30
+
+
+@pytest.mark.parametrize("shape,nprocs,in_place", [((16, 12, 16), 2, 0), ((24, 10, 23), 3, 0), ((32, 8, 48), 4, 1)])
+def test_native_rccl_ranks_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_place):
+    """The library's OWN RCCL transport with MORE THAN ONE rank: one process per rank, each with a
+    communicator made by ncclCommInitRank from the id rank 0 created (ekpnp_comm_unique_id ->
+    ekpnp_slab_attach_comm), halo ring by ncclSend/ncclRecv, interface coefficients by ncclAllGather,
+    diagnostics by ncclAllReduce, whole-lattice files by the ranks taking turns.  RCCL refuses two ranks
+    of one HOST on one device, so every rank claims its own host id (NCCL_HOSTID) and RCCL wires them
+    through its socket transport - the library's side is the multi-GPU code path unchanged.  Checked:
+    fields vs the single-context run (uneven slabs included), combined diagnostics on every rank, the
+    data_end / Tecplot files byte for byte against the single context's, bitwise continuation from
+    per-rank checkpoints, and the reference's restart route through the collective reader."""
+    p = pkg.default_params(*shape)
+    p.pb_iterations = 12
+    po = O.default_params(*shape)
+    _, st, want = _single(pkg, O, p, lambda f: O.perturb_fields(po, f), 6)
+    with pkg.Solver(p) as ref:
+        ref.set_fields(want)
+        want_current, want_umax = ref.current(), ref.umax()
+        ref.save_data_end(str(tmp_path / "single_end.dat"), 0.25)
+        ref.save_data_tecplot(str(tmp_path / "single_tec.dat"), 0.25)
+    np.savez(tmp_path / "start.npz", **st)
+    env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_IN_PLACE=str(in_place), EKPNP_SLAB_GRID="x".join(map(str, shape)),
+               OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nprocs}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rccl_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-4000:]
+    parts = sorted((np.load(tmp_path / f"rank{k}.npz") for k in range(nprocs)), key=lambda d: int(d["z0"]))
+    got = {k: np.concatenate([d[k] for d in parts], axis=0) for k in O.FIELDS}
+    err = O.rel_l2(got, want)
+    assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err
+    for d in parts:
+        assert abs(float(d["current"]) - want_current) <= 1e-9 * abs(want_current)
+        assert abs(float(d["umax"]) - want_umax) <= 1e-6 * abs(want_umax) + 1e-30
+        assert bool(d["ckpt_same"]) and float(d["t_ck"]) == pytest.approx(6 * p.dt, rel=1e-12)
+        assert float(d["t_read"]) == pytest.approx(0.25, rel=1e-5)  # the file holds the time as %10.6f-style text
+    # the files the ranks wrote in turns: text of the SAME numbers as the single context's whenever the fields agree to
+    # the printed digits; the slab fields equal the single context's to ~1e-13, so compare parsed values, then sizes
+    for mine, single in (("data_end.dat", "single_end.dat"), ("tec.dat", "single_tec.dat")):
+        a, b = (tmp_path / mine).read_text().splitlines(), (tmp_path / single).read_text().splitlines()
+        assert len(a) == len(b) and len(a) >= np.prod(shape), (mine, len(a), len(b))
+        skip = len(a) - int(np.prod(shape))
+        assert a[:skip] == b[:skip], (mine, a[:skip], b[:skip])
+        va = np.array([x.split() for x in a[skip:]], dtype=np.float64)
+        vb = np.array([x.split() for x in b[skip:]], dtype=np.float64)
+        scale = np.abs(vb).max(axis=0) + 1e-300
+        assert (np.abs(va - vb) / scale).max() < 1e-5, (mine, (np.abs(va - vb) / scale).max())
+    # restart through the collective reader: the fields the ranks hold afterwards are the file's (text precision);
+    # interior planes only - the writer extrapolates rho, c, cn, u onto the plates (LBM.cu:2527-2542)
+    re = {k: np.concatenate([d["re_" + k] for d in parts], axis=0) for k in ("rho", "c", "cn", "T")}
+    for k, v in re.items():
+        assert np.abs(v[1:-1] - want[k][1:-1]).max() <= 2e-6 * max(1.0, np.abs(want[k]).max()), k

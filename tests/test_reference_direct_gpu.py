@@ -316,3 +316,91 @@ def test_reference_kernels_live_at_cfg2_scale(pkg, O, tmp_path):
             inject_leak(s, p, leak_of(ref["phi"], s.get_field("phi")))
             _check(O, name, step, s.fields(), ref, wall_fraction=1.0)
             os.remove(tmp_path / f"L_step{step}.bin")
+
+
+# ---- G4: the reference's POPULATIONS, kernel by kernel, against the HIP path's own state ------------------
+# D3Q27 directions in the reference's numbering (SURVEY.md 8(a) a1; LBM.cu:1983-2008): c[d] = (cx, cy, cz)
+_C27 = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (1, 1, 0), (-1, -1, 0), (1, 0, 1), (-1, 0, -1),
+        (0, 1, 1), (0, -1, -1), (1, -1, 0), (-1, 1, 0), (1, 0, -1), (-1, 0, 1), (0, 1, -1), (0, -1, 1), (1, 1, 1), (-1, -1, -1),
+        (1, 1, -1), (-1, -1, 1), (1, -1, 1), (-1, 1, -1), (-1, 1, 1), (1, -1, -1)]
+
+
+def _checkpoint_populations(path, p):
+    """[lattice][z][y][x][27]: the post-collision populations of a whole-lattice EKPNPCK1 file (layout documented
+    in include/ekpnp.h / io.hip: 64-byte header, 11 fields, then per lattice NZ planes of [y][x/64][27][64])."""
+    nx, ny, nz, nl = p.nx, p.ny, p.nz, p.n_lattices
+    tiles = (nx + 63) // 64
+    raw = np.fromfile(path, dtype=np.float64, offset=64)
+    nf = 11 * nx * ny * nz
+    pops = raw[nf:].reshape(nl, nz, ny, tiles, 27, 64)
+    assert raw.size == nf + pops.size
+    return np.moveaxis(pops, 4, 5).reshape(nl, nz, ny, tiles * 64, 27)[:, :, :, :nx, :]
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_G4_populations_hip_vs_reference_direct(pkg, O, grid, tmp_path):
+    """SURVEY.md 8(c) G4 - populations of all four lattices dumped by the reference after each of its launches
+    (LBM.cu:474-477) - against the HIP path's state, read through the public ekpnp_save_checkpoint.  The HIP path
+    keeps POST-COLLISION populations and streams them by pulling in the next sweep, so on the interior planes
+      * its state after a sweep IS the reference's X0 / X2 after gpu_collide_save (stage "collide", and the rest
+        population X0 of stage "step1");
+      * that state shifted by c_d (gpu_stream, LBM.cu:1963-2093, periodic in x and y) IS the reference's X1 after the
+        whole stream_collide_save on the planes 2..NZ-3, whose sources are interior nodes (stages "step1", "bc_charge").
+    The wall planes, where the reference's gpu_boundary / gpu_bc_charge rewrite populations that the HIP wall kernel
+    folds into its own private form, are covered by the field-level comparisons above.  Sampled nodes: the z, y, x
+    selections the fixture holds (both sides of a 64-node tile boundary on the wide grids)."""
+    G = _Gold(pkg, grid)
+    p = G.p
+    if grid == "50x8x51":
+        g4 = _need("ref_g4.npz")
+        key = lambda stage: g4[stage + "_sample"]  # noqa: E731
+        zs, xs, ys, shift = list(g4["zsel"]), list(g4["xsel"]), list(g4["ysel"]), float(g4["shift"])
+    else:
+        g4 = G.g2
+        key = lambda stage: g4[f"g4_{stage}_sample"]  # noqa: E731
+        zs, xs, ys, shift = list(g4["g4_zsel"]), list(g4["g4_xsel"]), list(g4["ysel"]), float(g4["g4_shift"])
+    nz = p.nz
+    ck = str(tmp_path / "state.ck")
+
+    def state(s):
+        s.save_checkpoint(ck)
+        return _checkpoint_populations(ck, p)
+
+    def streamed(P):  # X1[d](x) = X2[d](x - c_d)
+        out = np.empty_like(P)
+        for d, (cx, cy, cz) in enumerate(_C27):
+            out[..., d] = np.roll(P[..., d], (cz, cy, cx), axis=(1, 2, 3))
+        return out
+
+    def compare(P, stage, zmin, zmax, dirs):
+        ref = key(stage)  # [4][27][len(zs)][len(ys)][len(xs)]
+        worst = 0.0
+        for iz, z in enumerate(zs):
+            if not zmin <= z <= zmax:
+                continue
+            got = P[:, z][:, ys][:, :, xs]  # [4][ys][xs][27]
+            for d in dirs:
+                r = ref[:, d, iz]
+                scale = np.abs(ref[:, d]).max(axis=(1, 2, 3))[:, None, None]
+                worst = max(worst, float((np.abs(got[..., d] - r) / scale).max()))
+        return worst
+
+    with pkg.Solver(p) as s:
+        s.call("init_fields")
+        s.set_fields({k: G.g2[f"{G.k2}input_{k}"] for k in ("rho", "c", "cn", "T", "ux", "uy", "uz")})
+        s.fast_Poisson()
+        inject_leak(s, p, shift)
+        s.init_equilibrium()
+        s.stream_collide_save()
+        P1 = state(s)
+        s.stream_collide_save()  # the reference's dump launches the four kernels again without a solve in between
+        P2 = state(s)
+    rec = {
+        "step1_rest": compare(P1, "step1", 1, nz - 2, [0]),
+        "step1_streamed": compare(streamed(P1), "step1", 2, nz - 3, range(1, 27)),
+        "collide": compare(P2, "collide", 1, nz - 2, range(27)),
+        "stream": compare(streamed(P2), "stream", 2, nz - 3, range(1, 27)),
+        "bc_charge": compare(streamed(P2), "bc_charge", 2, nz - 3, range(1, 27)),
+    }
+    _REPORT.append({"test": f"G4_direct[{grid}]", "mark": "populations", "max_rel_dev": rec})
+    assert sum(1 for z in zs if 2 <= z <= nz - 3) >= 1 and max(rec.values()) <= 1e-12, rec

@@ -58,10 +58,18 @@ def main():
     s.step(3)
     again = s.fields()
     same = all(np.array_equal(cont[k], again[k]) for k in cont)
+    # a file that cannot be opened: EVERY rank gets the error (the ranks agree on the status between the turns),
+    # nobody hangs, and the transport keeps working afterwards
+    try:
+        s.save_data_end(os.path.join(out, "no_such_directory", "x.dat"), 0.25)
+        io_error = ""
+    except pkg.EkpnpError as e:
+        io_error = str(e)
+    umax_after = s.umax()
     # the reference's restart route (fields -> equilibrium), collective read of the whole-lattice file
     t_read = s.read_data(os.path.join(out, "data_end.dat"))
     reread = s.fields()
-    np.savez(os.path.join(out, f"rank{rank}.npz"), z0=s.z0, current=current, umax=umax, ckpt_same=same, t_ck=t_ck, t_read=t_read,
+    np.savez(os.path.join(out, f"rank{rank}.npz"), z0=s.z0, current=current, umax=umax, ckpt_same=same, t_ck=t_ck, t_read=t_read, io_error=io_error, umax_after=umax_after,
              **fields, **{"re_" + k: v for k, v in reread.items()})
     dist.barrier()
     s.close()

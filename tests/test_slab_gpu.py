@@ -176,6 +176,7 @@ def test_native_rccl_ranks_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_p
         assert abs(float(d["umax"]) - want_umax) <= 1e-6 * abs(want_umax) + 1e-30
         assert bool(d["ckpt_same"]) and float(d["t_ck"]) == pytest.approx(6 * p.dt, rel=1e-12)
         assert float(d["t_read"]) == pytest.approx(0.25, rel=1e-5)  # the file holds the time as %10.6f-style text
+        assert str(d["io_error"]) != "" and np.isfinite(float(d["umax_after"]))  # a failed open reaches every rank; no hang
     # the files the ranks wrote in turns: text of the SAME numbers as the single context's whenever the fields agree to
     # the printed digits; the slab fields equal the single context's to ~1e-13, so compare parsed values, then sizes
     for mine, single in (("data_end.dat", "single_end.dat"), ("tec.dat", "single_tec.dat")):

@@ -348,23 +348,10 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
     int n[2] = {p->ny, p->nx};
     int rembed[2] = {p->ny, p->nx};      // real planes, dense
     int cembed[2] = {p->ny, c.nxh};      // half spectrum with the padded row pitch
-    // 512-row planes: rocFFT transforms the rows (x), the columns (y) are the library's own kernel (fft_y.hip);
-    // EKPNP_OWN_YFFT=0 keeps rocFFT's 2-D plan (the A/B partner)
-    const char* own = std::getenv("EKPNP_OWN_YFFT");
-    c.own_yfft = c.fft_nz > 0 && fft_y_supported(p->ny, c.nxh) && !(own && own[0] == '0');
-    hipfftResult r;
-    if (c.own_yfft) {
-      if ((rc = fft_y_make_table(c))) return bail(rc);
-      r = hipfftPlanMany(&c.plan_fwd, 1, n + 1, rembed + 1, 1, p->nx, cembed + 1, 1, c.nxh, HIPFFT_D2Z, p->ny * c.fft_nz);
-    } else {
-      r = hipfftPlanMany(&c.plan_fwd, 2, n, rembed, 1, p->ny * p->nx, cembed, 1, p->ny * c.nxh, HIPFFT_D2Z, c.fft_nz);
-    }
+    hipfftResult r = hipfftPlanMany(&c.plan_fwd, 2, n, rembed, 1, p->ny * p->nx, cembed, 1, p->ny * c.nxh, HIPFFT_D2Z, c.fft_nz);
     if (r != HIPFFT_SUCCESS) { c.plan_fwd = 0; c.err = "hipfftPlanMany (D2Z) failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
     c.have_fwd = true;
-    if (c.own_yfft)
-      r = hipfftPlanMany(&c.plan_inv, 1, n + 1, cembed + 1, 1, c.nxh, rembed + 1, 1, p->nx, HIPFFT_Z2D, p->ny * c.fft_nz);
-    else
-      r = hipfftPlanMany(&c.plan_inv, 2, n, cembed, 1, p->ny * c.nxh, rembed, 1, p->ny * p->nx, HIPFFT_Z2D, c.fft_nz);
+    r = hipfftPlanMany(&c.plan_inv, 2, n, cembed, 1, p->ny * c.nxh, rembed, 1, p->ny * p->nx, HIPFFT_Z2D, c.fft_nz);
     if (r != HIPFFT_SUCCESS) { c.plan_inv = 0; c.err = "hipfftPlanMany (Z2D) failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
     c.have_inv = true;
     c.plans = true;
@@ -416,7 +403,6 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
     if (c.halo[k]) (void)hipFree(c.halo[k]);
     if (c.phi_halo[k]) (void)hipFree(c.phi_halo[k]);
   }
-  if (c.fft_tw) (void)hipFree(c.fft_tw);
   if (c.have_fwd) hipfftDestroy(c.plan_fwd);
   if (c.have_inv) hipfftDestroy(c.plan_inv);
   for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -565,26 +551,14 @@ static int poisson_timing_mark(Ctx& c, bool begin) {
   return EKPNP_OK;
 }
 
-// the 2-D transforms of the owned interior planes: rocFFT's 2-D plan, or rocFFT rows + the library's own columns
-static int fft_forward(Ctx& c) {
-  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec()));
-  if (c.own_yfft) launch_fft_y(c, -1);
-  return EKPNP_OK;
-}
-static int fft_inverse(Ctx& c) {
-  if (c.own_yfft) launch_fft_y(c, +1);
-  FFTCHK(c, hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out()));
-  return EKPNP_OK;
-}
-
 static int poisson_single(Ctx& c) {
   int trc = poisson_timing_mark(c, true);
   if (trc) return trc;
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
-  if (int rc = fft_forward(c)) return rc;
+  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec()));
   launch_tridiag(c);
-  if (int rc = fft_inverse(c)) return rc;
+  FFTCHK(c, hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out()));
   launch_phi_efield(c);
   LAUNCHCHK(c);
   return poisson_timing_mark(c, false);
@@ -1054,7 +1028,7 @@ extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
   }
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
-  if (int rc = fft_forward(c)) return rc;
+  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec()));
   launch_slab_thomas_local(c);
   LAUNCHCHK(c);
   return EKPNP_OK;
@@ -1073,7 +1047,7 @@ extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   launch_slab_reduce_correct(c);
-  if (int rc = fft_inverse(c)) return rc;
+  FFTCHK(c, hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out()));
   LAUNCHCHK(c);
   return EKPNP_OK;
 }

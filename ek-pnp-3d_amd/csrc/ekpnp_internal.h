@@ -140,9 +140,6 @@ void launch_halo_unpack(Ctx&);
 int build_cprime(Ctx&);  // EKPNP_OK or a status with Ctx::err set
 void launch_poisson_rhs(Ctx&);
 void launch_tridiag(Ctx&);
-bool fft_y_supported(int ny, int nxh);
-int fft_y_make_table(Ctx&);
-void launch_fft_y(Ctx&, int sign);  // in place on the owned interior planes of the spectrum; -1 forward, +1 inverse
 void launch_phi_efield(Ctx&);
 void launch_slab_thomas_local(Ctx&);
 void launch_slab_reduce_correct(Ctx&);
@@ -222,9 +219,6 @@ struct Ctx {
   int graph_cur = -1;              // value of `cur` the graph was captured at
   bool graph_failed = false;       // capture is not possible here: stay eager
   hipfftHandle plan_fwd = 0, plan_inv = 0;
-  // planes of 512 rows: the library's own y pass (fft_y.hip); plan_fwd / plan_inv are then the batched 1-D x transforms
-  bool own_yfft = false;
-  double2* fft_tw = nullptr;  // exp(-2 pi i k / 512)
   bool have_fwd = false, have_inv = false;  // each handle is destroyed on its own (a failing second plan must not leak the first)
   bool plans = false;
   double t = 0.0;

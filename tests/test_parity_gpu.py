@@ -711,35 +711,3 @@ def test_anisotropic_spacings_vs_oracle(pkg, O):
     po.dy, po.dz = 1.7e-8, 0.8e-8
     po.Lx, po.Ly, po.Lz = 40 * 1.0e-8 * 1.3, 12 * 1.7e-8, 20 * 0.8e-8
     _assert_all(_run_pair(pkg, O, po, [1, 6]), name="anisotropic_spacings")
-
-
-@pytest.mark.parametrize("shape,slabs", [((128, 512, 9), 1), ((64, 512, 20), 1), ((640, 512, 6), 1), ((128, 512, 24), 3)])
-def test_own_y_transform_equals_rocfft_2d(pkg, O, shape, slabs, monkeypatch):
-    """Planes of 512 rows: the y pass of the 2-D transforms is the library's own kernel (fft_y.hip: 8
-    columns per workgroup, radix 8 x 8 x 8 through LDS) behind rocFFT's row transforms.  EKPNP_OWN_YFFT=0
-    builds the A/B partner with rocFFT's 2-D plan; fast_Poisson of random charges must agree to rounding
-    (two FFT algorithms: ~1e-15 of the largest |phi|, E accordingly), also over slabs."""
-    rng = np.random.default_rng(5)
-    p = pkg.default_params(*shape)
-    cc, cn = 0.01 * (1 + 0.5 * rng.random(shape[::-1])), 0.01 * (1 + 0.5 * rng.random(shape[::-1]))
-
-    def solve():
-        if slabs == 1:
-            with pkg.Solver(p) as s:
-                s.set_field("c", cc)
-                s.set_field("cn", cn)
-                s.fast_Poisson()
-                return {k: s.get_field(k) for k in ("phi", "Ex", "Ey", "Ez")}
-        with pkg.Group(p, slabs, devices=[0] * slabs) as g:
-            g.set_field("c", cc)
-            g.set_field("cn", cn)
-            g.fast_Poisson()
-            return {k: g.get_field(k) for k in ("phi", "Ex", "Ey", "Ez")}
-
-    monkeypatch.setenv("EKPNP_OWN_YFFT", "0")
-    want = solve()
-    monkeypatch.delenv("EKPNP_OWN_YFFT")
-    got = solve()
-    err = O.rel_l2(got, want, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
-    assert err["phi"] < 1e-14 and err["E"] < 1e-12, err
-    assert not np.array_equal(got["phi"], want["phi"])  # the two builds really took different routes

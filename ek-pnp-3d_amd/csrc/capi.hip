@@ -265,14 +265,22 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   // (profiles/r02_population_arena.log).  EKPNP_POP_ARENA=<bytes> puts a gap between the buffers (0 and
   // 4096 measured the same), EKPNP_POP_ARENA=-1 restores one allocation per buffer (the A/B partner).
   static const long long arena_gap = std::getenv("EKPNP_POP_ARENA") ? std::atoll(std::getenv("EKPNP_POP_ARENA")) : 0;
-  if (arena_gap >= 0) {
+  bool arena = arena_gap >= 0;
+  if (arena) {
     const int nbuf = (c.inplace ? 1 : 2) * p->n_lattices;
     const size_t pitch = (popbytes + (size_t)arena_gap + 255) / 256 * 256;
-    if ((rc = dev_alloc(c, &c.pop_alloc[0][0], pitch * nbuf))) return bail(rc);
-    int k = 0;
-    for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
-      for (int l = 0; l < p->n_lattices; ++l, ++k) c.pop[b][l] = (double*)((char*)c.pop_alloc[0][0] + pitch * k);
-  } else {
+    if (hipMalloc(&c.pop_alloc[0][0], pitch * nbuf) == hipSuccess) {
+      c.bytes += pitch * nbuf;
+      int k = 0;
+      for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
+        for (int l = 0; l < p->n_lattices; ++l, ++k) c.pop[b][l] = (double*)((char*)c.pop_alloc[0][0] + pitch * k);
+    } else {  // no contiguous range of that size (a fragmented device): one allocation per buffer may still fit
+      (void)hipGetLastError();
+      c.pop_alloc[0][0] = nullptr;
+      arena = false;
+    }
+  }
+  if (!arena) {
     for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
       for (int l = 0; l < p->n_lattices; ++l) {
         if ((rc = dev_alloc(c, &c.pop_alloc[b][l], popbytes))) return bail(rc);

@@ -46,6 +46,12 @@ def main():
     s.synchronize()
     current, umax = s.current(), s.umax()  # all-reduce inside the library
     fields = s.fields()
+    if os.environ.get("EKPNP_RCCL_FIELDS_ONLY") == "1":  # full-width planes: fields and diagnostics only (the text files would be GBs)
+        np.savez(os.path.join(out, f"rank{rank}.npz"), z0=s.z0, current=current, umax=umax, **fields)
+        dist.barrier()
+        s.close()
+        dist.destroy_process_group()
+        return
     # whole-lattice files, written plane by plane in rank order by the ranks taking turns
     s.save_data_end(os.path.join(out, "data_end.dat"), 0.25)
     s.save_data_tecplot(os.path.join(out, "tec.dat"), 0.25)

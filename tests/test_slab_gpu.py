@@ -193,3 +193,31 @@ def test_native_rccl_ranks_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_p
     re = {k: np.concatenate([d["re_" + k] for d in parts], axis=0) for k in ("rho", "c", "cn", "T")}
     for k, v in re.items():
         assert np.abs(v[1:-1] - want[k][1:-1]).max() <= 2e-6 * max(1.0, np.abs(want[k]).max()), k
+
+
+def test_native_rccl_two_ranks_full_width_planes(pkg, O, tmp_path):
+    """Two real RCCL ranks (as above) on planes of cfg3's full width: 512 x 512 x 24, i.e. 8 tiles per row,
+    the two-node phi / E kernel, 37.7 MB halo messages per direction and lattice group - against the single
+    context on the same lattice (fields and combined diagnostics)."""
+    shape, nprocs = (512, 512, 24), 2
+    p = pkg.default_params(*shape)
+    p.pb_iterations = 12
+    po = O.default_params(*shape)
+    _, st, want = _single(pkg, O, p, lambda f: O.perturb_fields(po, f), 6)
+    with pkg.Solver(p) as ref:
+        ref.set_fields(want)
+        want_current, want_umax = ref.current(), ref.umax()
+    np.savez(tmp_path / "start.npz", **st)
+    env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_IN_PLACE="0", EKPNP_SLAB_GRID="x".join(map(str, shape)),
+               EKPNP_RCCL_FIELDS_ONLY="1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nprocs}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rccl_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    parts = sorted((np.load(tmp_path / f"rank{k}.npz") for k in range(nprocs)), key=lambda d: int(d["z0"]))
+    got = {k: np.concatenate([d[k] for d in parts], axis=0) for k in O.FIELDS}
+    err = O.rel_l2(got, want)
+    assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err
+    for d in parts:
+        assert abs(float(d["current"]) - want_current) <= 1e-9 * abs(want_current)
+        assert abs(float(d["umax"]) - want_umax) <= 1e-6 * abs(want_umax) + 1e-30

@@ -86,6 +86,7 @@ extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
   Ctx& c = ctx->c;
   if (std::strcmp(knob, "ab_zchunk") == 0 && value >= 0) { c.ab_zchunk = value; return EKPNP_OK; }
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
+  if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
   c.err = "ekpnp_tune: unknown knob or bad value";
   return EKPNP_ERR_INVALID;
 }
@@ -249,6 +250,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   if (hipGetDevice(&c.device) != hipSuccess) { c.err = "hipGetDevice failed"; return bail(EKPNP_ERR_HIP); }
   if (const char* e = std::getenv("EKPNP_BULK_ZCHUNK")) c.ab_zchunk = std::atoi(e) > 0 ? std::atoi(e) : 0;
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
+  if (const char* e = std::getenv("EKPNP_TRI_PARTITION")) c.tri_partition = std::atoi(e) < 0 ? 0 : (std::atoi(e) > 2 ? 2 : std::atoi(e));
   // In-place mode: one buffer per lattice with `shift` spare planes.  A sweep writes plane z of
   // the new state `shift` planes below (parity 0, bulk launches of `zchunk` planes in ascending z)
   // or above (parity 1, descending) where plane z of the old state lies; shift >= zchunk + 1

@@ -219,6 +219,7 @@ struct Ctx {
   int graph_cur = -1;              // value of `cur` the graph was captured at
   bool graph_failed = false;       // capture is not possible here: stay eager
   hipfftHandle plan_fwd = 0, plan_inv = 0;
+  int tri_partition = 1;  // z solve of a single context: 0 serial sweeps, 1 partition solve on large lattices, 2 wherever it applies
   bool have_fwd = false, have_inv = false;  // each handle is destroyed on its own (a failing second plan must not leak the first)
   bool plans = false;
   double t = 0.0;

@@ -156,6 +156,130 @@ __global__ void __launch_bounds__(EKPNP_TRI_THREADS) k_tridiag(PArgs a) {
   }
 }
 
+// Channels of 66 < NZ <= 64 R + 2 planes on large lattices: the z solve with the spectrum read ONCE.
+// k_tridiag above reads every row twice (3.4 GB on 512^3) because one thread cannot hold a column; here a
+// whole wavefront holds it: lane l keeps R consecutive rows (slots R l .. R l + R - 1; row = slot + 1) of
+// one (kx,ky) mode in registers, and the system  x[i-1] + b x[i] + x[i+1] = dz^2 r[i]  is solved by the
+// partition method:
+//   * every lane eliminates its R-1 interior rows (a Thomas sweep of R-1 rows, three right-hand sides:
+//     the data g and the unit couplings v, w to the interface unknowns y[l-1], y[l] = the lane's last row);
+//   * the interface rows form a tridiagonal system of 64 unknowns across the lanes, solved by parallel
+//     cyclic reduction in 6 shuffle steps (as k_tridiag_pcr64);
+//   * x = g - y[l-1] v - y[l] w.
+// Rows beyond NZ-2 are identity rows.  A workgroup takes 8 adjacent modes (one 128-byte line per row): the
+// rows come in coalesced (thread (c, t): rows t + 64 r of column c), change owner through a 64 R x 8 LDS
+// image (column index XOR-swizzled by the owning lane: the solve-phase reads are 2-way, the rest
+// conflict-free) and leave the same way.  Same system, different elimination order than k_tridiag:
+// results agree to rounding (tests/test_parity_gpu.py::test_partition_z_solve...).
+template <int R>
+__global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
+  extern __shared__ double2 tp_lds[];  // [64 R slots][8 columns]
+  const long long ms = (long long)a.ny * a.nxh;
+  const int n = a.nz - 2;
+  const long long m0 = (long long)blockIdx.x * 8;
+  {
+    const int c = threadIdx.x & 7, t = threadIdx.x >> 3;
+    const double2* src = a.spec + m0 + c;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int s = t + 64 * r;
+      double2 v = make_double2(0.0, 0.0);
+      if (s < n) v = src[(long long)(s + 1) * ms];
+      tp_lds[s * 8 + (c ^ ((s / R) & 7))] = v;
+    }
+  }
+  __syncthreads();
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const double b = mode_diag((int)(m0 + w), a.ny, a.nxh, a.Lx, a.Ly, a.dz);
+  const double dz2 = a.dz * a.dz;
+  double2* mine = tp_lds + (R * l) * 8 + (w ^ (l & 7));
+  double2 g[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const double2 r = mine[k * 8];
+    g[k] = make_double2(dz2 * r.x, dz2 * r.y);
+  }
+  // interior rows k = 0 .. R-2 of this lane
+  double cp[R - 1], v[R - 1], wv[R - 1];
+  {
+    double cprev = 0.0, vprev = 0.0;
+    double2 gprev = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < R - 1; ++k) {
+      const int s = R * l + k;
+      const bool real = s < n;
+      const double Ain = (real && k > 0) ? 1.0 : 0.0;               // coupling to the row before, inside the block
+      const double A0 = (real && k == 0 && s > 0) ? 1.0 : 0.0;      // coupling of the first row to y[l-1]
+      const double Bk = real ? b : 1.0;
+      const double Cany = (real && s < n - 1) ? 1.0 : 0.0;          // coupling to the row after
+      const double inv = 1.0 / (Bk - Ain * cprev);
+      cp[k] = (k < R - 2 ? Cany : 0.0) * inv;
+      g[k] = make_double2((g[k].x - Ain * gprev.x) * inv, (g[k].y - Ain * gprev.y) * inv);
+      v[k] = (A0 - Ain * vprev) * inv;
+      wv[k] = (k == R - 2 ? Cany : 0.0) * inv;                      // rows before R-2 have no w right-hand side
+      cprev = cp[k];
+      vprev = v[k];
+      gprev = g[k];
+    }
+#pragma unroll
+    for (int k = R - 3; k >= 0; --k) {
+      g[k] = make_double2(g[k].x - cp[k] * g[k + 1].x, g[k].y - cp[k] * g[k + 1].y);
+      v[k] = v[k] - cp[k] * v[k + 1];
+      wv[k] = -cp[k] * wv[k + 1];
+    }
+  }
+  // the interface row (slot R l + R - 1) in terms of y[l-1], y[l], y[l+1]
+  double lo, up, bd, rr, ri;
+  {
+    const int s = R * l + R - 1;
+    const bool real = s < n;
+    const double A7 = real ? 1.0 : 0.0, B7 = real ? b : 1.0, C7 = (real && s < n - 1) ? 1.0 : 0.0;
+    const double g0x = __shfl_down(g[0].x, 1, 64), g0y = __shfl_down(g[0].y, 1, 64);
+    const double v0n = __shfl_down(v[0], 1, 64), w0n = __shfl_down(wv[0], 1, 64);
+    lo = -A7 * v[R - 2];
+    bd = B7 - A7 * wv[R - 2] - C7 * v0n;
+    up = -C7 * w0n;
+    rr = g[R - 1].x - A7 * g[R - 2].x - C7 * g0x;
+    ri = g[R - 1].y - A7 * g[R - 2].y - C7 * g0y;
+    if (l == 63) up = 0.0;
+    if (l == 0) lo = 0.0;
+  }
+#pragma unroll
+  for (int st = 1; st < 64; st <<= 1) {
+    const bool hl = l - st >= 0, hu = l + st < 64;
+    double lo_l = __shfl_up(lo, st, 64), up_l = __shfl_up(up, st, 64), bd_l = __shfl_up(bd, st, 64);
+    double rr_l = __shfl_up(rr, st, 64), ri_l = __shfl_up(ri, st, 64);
+    double lo_u = __shfl_down(lo, st, 64), up_u = __shfl_down(up, st, 64), bd_u = __shfl_down(bd, st, 64);
+    double rr_u = __shfl_down(rr, st, 64), ri_u = __shfl_down(ri, st, 64);
+    if (!hl) { lo_l = 0.0; up_l = 0.0; bd_l = 1.0; rr_l = 0.0; ri_l = 0.0; }
+    if (!hu) { lo_u = 0.0; up_u = 0.0; bd_u = 1.0; rr_u = 0.0; ri_u = 0.0; }
+    const double al = -lo / bd_l, ga = -up / bd_u;
+    bd = bd + al * up_l + ga * lo_u;
+    rr = rr + al * rr_l + ga * rr_u;
+    ri = ri + al * ri_l + ga * ri_u;
+    lo = al * lo_l;
+    up = ga * up_u;
+  }
+  const double yx = rr / bd, yy = ri / bd;
+  double ylx = __shfl_up(yx, 1, 64), yly = __shfl_up(yy, 1, 64);
+  if (l == 0) { ylx = 0.0; yly = 0.0; }
+  // 1/(NX NY) of the unnormalised transforms folded in, as in k_tridiag
+#pragma unroll
+  for (int k = 0; k < R - 1; ++k)
+    mine[k * 8] = make_double2((g[k].x - ylx * v[k] - yx * wv[k]) * a.inv_nxny, (g[k].y - yly * v[k] - yy * wv[k]) * a.inv_nxny);
+  mine[(R - 1) * 8] = make_double2(yx * a.inv_nxny, yy * a.inv_nxny);
+  __syncthreads();
+  {
+    const int c = threadIdx.x & 7, t = threadIdx.x >> 3;
+    double2* dst = a.spec + m0 + c;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int s = t + 64 * r;
+      if (s < n) TRI_STORE(dst + (long long)(s + 1) * ms, tp_lds[s * 8 + (c ^ ((s / R) & 7))]);
+    }
+  }
+}
+
 // Short channels (NZ - 2 <= 64 unknown rows, e.g. the reference's own 51 planes): the serial
 // sweeps above are a chain of ~2 NZ dependent loads per mode and dominate a step that is only
 // tens of microseconds long.  Here one wave64 owns one (kx,ky) mode, lane i holds row i + 1, and
@@ -710,8 +834,18 @@ void launch_poisson_rhs(Ctx& c) {
 void launch_tridiag(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
-  if (c.p.nz - 2 <= 64)
+  // c.tri_partition (ekpnp_tune "tri_partition" / EKPNP_TRI_PARTITION): 0 the serial sweeps everywhere (the A/B
+  // partner of k_tridiag_part), 1 the partition solve on large lattices, 2 wherever it applies (tests)
+  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_part<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 8 * 8 * (int)sizeof(double2)) == hipSuccess;
+  const bool part = c.tri_partition > 0 && lds_ok && c.nxh % 8 == 0;
+  const int rows = c.p.nz - 2;
+  const bool large = c.tri_partition > 1 || (size_t)nm * (size_t)rows >= (size_t)4 * 1024 * 1024;  // enough modes to fill the chip 8 at a time
+  if (rows <= 64)
     hipLaunchKernelGGL(k_tridiag_pcr64, dim3((nm + 3) / 4), dim3(256), 0, c.stream, a);
+  else if (part && large && rows <= 256)
+    hipLaunchKernelGGL(k_tridiag_part<4>, dim3(nm / 8), dim3(512), 64 * 4 * 8 * sizeof(double2), c.stream, a);
+  else if (part && large && rows <= 512)
+    hipLaunchKernelGGL(k_tridiag_part<8>, dim3(nm / 8), dim3(512), 64 * 8 * 8 * sizeof(double2), c.stream, a);
   else
     hipLaunchKernelGGL(k_tridiag, dim3((nm + EKPNP_TRI_THREADS - 1) / EKPNP_TRI_THREADS), dim3(EKPNP_TRI_THREADS), 0, c.stream, a);
   note_launch(c, "k_tridiag");

@@ -237,7 +237,9 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
  * planes per launch of the two-buffer collide sweep (0 = the whole sweep in one launch).
  * "merged_walls": 1 (default) = lattices of up to 4 M nodes collide plates and bulk in ONE launch,
  * 0 = always separate launches (what large lattices, in-place contexts and slabs do anyway); same
- * results bit for bit. */
+ * results bit for bit.  "tri_partition": the z solve of a single context - 0 = the serial Thomas sweeps
+ * everywhere, 1 (default) = the partition solve (spectrum read once) on large lattices of 67 to 514 planes,
+ * 2 = wherever it applies; the two solve the same system in a different elimination order (equal to rounding). */
 int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value);
 /* Every kernel launch of the library is checked: a rejected launch makes the entry point return
  * EKPNP_ERR_HIP with the KERNEL's name in ekpnp_last_error.  With EKPNP_DEBUG_SYNC set in the

@@ -180,7 +180,11 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
     constexpr int d = decltype(ic)::value;
     constexpr int cx = PULL ? ex_of(d) : 0, cy = PULL ? ey_of(d) : 0, cz = PULL ? ez_of(d) : 0;
     const double* rowp = src + ((long long)(zg - cz) * a.ny + ys[cy + 1]) * a.rowstride + d * 64;
+#ifdef EKPNP_NT_LOADS  // A/B partner: non-temporal loads (every population is pulled exactly once) LOSE 3 %, profiles/r02_sweep_nt_loads.log
+    f[d] = __builtin_nontemporal_load(rowp + xo[cx + 1]);
+#else
     f[d] = rowp[xo[cx + 1]];
+#endif
   });
 
   if constexpr (NL > 1) {

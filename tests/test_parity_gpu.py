@@ -735,3 +735,25 @@ def test_partition_z_solve_equals_serial_sweeps(pkg, O, shape):
     # rounding of two elimination orders; the low modes of a tall channel are the ill-conditioned ones (cond ~ NZ^2)
     assert err["phi"] < 1e-12 and err["E"] < 1e-10, err
     assert not np.array_equal(out[0]["phi"], out[1]["phi"])  # two different kernels did run
+
+
+def test_partition_z_solve_random_channel_heights(pkg, O):
+    """the same comparison over 10 seeded random channel heights between 67 and 514 planes (every remainder of
+    the 64 x R slot grid: last lane full, partly full, empty) and random small cross-sections"""
+    rng = np.random.default_rng(2026)
+    for _ in range(10):
+        nz = int(rng.integers(67, 515))
+        nx, ny = int(rng.integers(1, 150)), int(rng.integers(1, 12))
+        p = pkg.default_params(nx, ny, nz)
+        shape = (nz, ny, nx)
+        cc, cn = 0.01 * (1 + 0.5 * rng.random(shape)), 0.01 * (1 + 0.5 * rng.random(shape))
+        out = []
+        for knob in (0, 2):
+            with pkg.Solver(p) as s:
+                s.tune("tri_partition", knob)
+                s.set_field("c", cc)
+                s.set_field("cn", cn)
+                s.fast_Poisson()
+                out.append(s.get_field("phi"))
+        err = np.sqrt(((out[1] - out[0]) ** 2).sum() / (out[0] ** 2).sum())
+        assert err < 1e-12 and np.isfinite(out[1]).all(), (nx, ny, nz, err)

@@ -171,6 +171,18 @@ __global__ void __launch_bounds__(EKPNP_TRI_THREADS) k_tridiag(PArgs a) {
 // image (column index XOR-swizzled by the owning lane: the solve-phase reads are 2-way, the rest
 // conflict-free) and leave the same way.  Same system, different elimination order than k_tridiag:
 // results agree to rounding (tests/test_parity_gpu.py::test_partition_z_solve...).
+// 1/x for the well-scaled pivots of the partition solve (|x| >= 1, finite): hardware reciprocal + two Newton steps
+// (full double precision to an ulp; the IEEE division sequence with its scaling and fix-up costs twice the instructions)
+__device__ __forceinline__ double recip(double x) {
+#ifdef EKPNP_TRI_IEEE_DIV
+  return 1.0 / x;
+#else
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#endif
+}
 template <int R>
 __global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
   extern __shared__ double2 tp_lds[];  // [64 R slots][8 columns]
@@ -212,7 +224,7 @@ __global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
       const double A0 = (real && k == 0 && s > 0) ? 1.0 : 0.0;      // coupling of the first row to y[l-1]
       const double Bk = real ? b : 1.0;
       const double Cany = (real && s < n - 1) ? 1.0 : 0.0;          // coupling to the row after
-      const double inv = 1.0 / (Bk - Ain * cprev);
+      const double inv = recip(Bk - Ain * cprev);
       cp[k] = (k < R - 2 ? Cany : 0.0) * inv;
       g[k] = make_double2((g[k].x - Ain * gprev.x) * inv, (g[k].y - Ain * gprev.y) * inv);
       v[k] = (A0 - Ain * vprev) * inv;
@@ -246,21 +258,21 @@ __global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
   }
 #pragma unroll
   for (int st = 1; st < 64; st <<= 1) {
-    const bool hl = l - st >= 0, hu = l + st < 64;
     double lo_l = __shfl_up(lo, st, 64), up_l = __shfl_up(up, st, 64), bd_l = __shfl_up(bd, st, 64);
     double rr_l = __shfl_up(rr, st, 64), ri_l = __shfl_up(ri, st, 64);
     double lo_u = __shfl_down(lo, st, 64), up_u = __shfl_down(up, st, 64), bd_u = __shfl_down(bd, st, 64);
     double rr_u = __shfl_down(rr, st, 64), ri_u = __shfl_down(ri, st, 64);
-    if (!hl) { lo_l = 0.0; up_l = 0.0; bd_l = 1.0; rr_l = 0.0; ri_l = 0.0; }
-    if (!hu) { lo_u = 0.0; up_u = 0.0; bd_u = 1.0; rr_u = 0.0; ri_u = 0.0; }
-    const double al = -lo / bd_l, ga = -up / bd_u;
+    // a lane without a partner at this distance has lo (up) == 0 - an invariant of the reduction, true of the start
+    // values - so whatever finite values its shuffle returned (its own) are multiplied by zero: no selects needed
+    const double al = -lo * recip(bd_l), ga = -up * recip(bd_u);
     bd = bd + al * up_l + ga * lo_u;
     rr = rr + al * rr_l + ga * rr_u;
     ri = ri + al * ri_l + ga * ri_u;
     lo = al * lo_l;
     up = ga * up_u;
   }
-  const double yx = rr / bd, yy = ri / bd;
+  const double ibd = recip(bd);
+  const double yx = rr * ibd, yy = ri * ibd;
   double ylx = __shfl_up(yx, 1, 64), yly = __shfl_up(yy, 1, 64);
   if (l == 0) { ylx = 0.0; yly = 0.0; }
   // 1/(NX NY) of the unnormalised transforms folded in, as in k_tridiag

@@ -5,10 +5,15 @@
 
 N=1: cfg3 of BASELINE.json (512x512x512, four D3Q27 lattices + Poisson) when it fits the GPU,
 otherwise cfg2 (256^3, f+h+hn).  N>1 (one rank per GPU: launched by torch.distributed.run, or by
-bench.py itself when invoked plainly - the ranks are then child processes): weak scaling, every
-rank owns a 512x512x512 slab of a 512x512x(512 N) channel (cfg4 at N=2), z-slab decomposition,
-halo exchange over RCCL inside libekpnp.so (ekpnp_slab_attach_comm); torch.distributed (gloo)
-is the control plane only: rendezvous, barrier, max over ranks.
+bench.py itself when invoked plainly - the ranks are then child processes) runs BASELINE.json's
+multi-GPU configurations BY NAME: N = 2..7 -> cfg4 (512x512x1024 split into N z slabs: 512 planes
+per rank at N=2 = the weak-scaling partner of cfg3@1, 256 at N=4 = strong scaling), N >= 8 -> cfg5
+(1024^3, 128 planes per rank at N=8: 134 M nodes per rank like cfg3@1, weak scaling);
+`--workload cfg4` is accepted at any N (128 planes per rank at N=8, the strong-scaling end),
+`--workload cfg3 --weak` keeps the 512^3-slab-per-rank channel of the earlier rounds, `--scale-z D`
+divides the z extent for rehearsals on a one-GPU box (labelled in the line).  z-slab decomposition,
+halo exchange over RCCL inside libekpnp.so (ekpnp_slab_attach_comm); torch.distributed (gloo) is
+the control plane only: rendezvous, barrier, max over ranks.
 
 One JSON line on rank 0.  `value` counts lattice-node updates of all ranks per wall second of
 the timed region (inputs resident in HBM, barrier + device sync on both sides, max over ranks).
@@ -75,6 +80,131 @@ def parse_workload(name: str, free_bytes: int, in_place: bool = False):
         return name, (64, 64, 64), 1, in_place
     nx, ny, nz = (int(v) for v in name.lower().split("x"))
     return name, (nx, ny, nz), 4, in_place
+
+
+CONFIGS = {  # BASELINE.json configs[0..4]: global grid, lattices
+    "cfg1": ((64, 64, 64), 1),
+    "cfg2": ((256, 256, 256), 3),
+    "cfg3": ((512, 512, 512), 4),
+    "cfg4": ((512, 512, 1024), 4),
+    "cfg5": ((1024, 1024, 1024), 4),
+}
+NODES_PER_RANK_AT_1 = 512**3  # cfg3, the N=1 line every N>1 line is compared with
+
+
+def device_need_bytes(nx: int, ny: int, nzl: int, nl: int, in_place: bool) -> int:
+    """device memory of one context / slab of nzl planes (csrc/capi.hip create_impl): tiled populations with two ghost
+    planes (+ the in-place shift), 11 fields + rhs + half spectrum"""
+    pplane = ((nx + 63) // 64) * 27 * 64 * ny * 8
+    shift = (min(max(nzl // 4, 1), 64) + 1) if in_place else 0
+    pops = (1 if in_place else 2) * nl * (nzl + 2 + shift) * pplane
+    return pops + 16 * nx * ny * nzl * 8
+
+
+def select_workload(name: str, world: int, free_bytes: int, in_place: bool = False, weak: bool = False, scale_z: int = 1) -> dict:
+    """Which lattice `bench.py --gpus world --workload name` runs, and what its line may call itself.
+
+    auto: N=1 -> cfg3 (cfg2 if it does not fit), N=2..7 -> cfg4, N>=8 -> cfg5.  Named grids are GLOBAL and split into
+    `world` z slabs; --weak makes the named grid ONE RANK's slab (the channel is `world` of them on top of each other).
+    `scaling` is "weak" when a rank owns as many nodes as the N=1 line's cfg3 (or with --weak), else "strong"."""
+    if world < 1 or world > 16:
+        raise ValueError("1 to 16 ranks (at most 16 z slabs)")
+    if scale_z < 1:
+        raise ValueError("--scale-z must be >= 1")
+    if name == "auto" and world > 1:
+        name = "cfg5" if world >= 8 else "cfg4"
+    if world == 1 and not weak and scale_z == 1:
+        wname, grid, nl, in_place = parse_workload(name, free_bytes, in_place)
+    else:
+        wname = "cfg3" if name == "auto" else name
+        if wname in CONFIGS:
+            grid, nl = CONFIGS[wname]
+        else:
+            grid, nl = tuple(int(v) for v in wname.lower().split("x")), 4
+            if len(grid) != 3:
+                raise ValueError(f"workload {wname!r}: cfg1..cfg5 or NXxNYxNZ")
+    nx, ny, nz = grid
+    if weak:
+        nz *= world
+    nz //= scale_z
+    if world > 1 and nz // world < 4:
+        raise ValueError(f"{nz} planes over {world} ranks: each z slab needs at least 4 planes")
+    planes = [(r + 1) * nz // world - r * nz // world for r in range(world)]
+    if world > 1 or weak or scale_z > 1:
+        if not in_place and free_bytes <= device_need_bytes(nx, ny, max(planes), nl, False) * 1.02:
+            in_place = True  # every rank takes the same decision: free_bytes is the minimum over the ranks
+    nodes_per_rank = nx * ny * nz / world
+    if world == 1:
+        scaling, note = "weak", "N=1: the line every N>1 line is compared with"
+    elif weak:
+        scaling, note = "weak", f"--weak: every rank owns a {grid[0]}x{grid[1]}x{grid[2] // scale_z} slab, the channel grows with N"
+    elif nodes_per_rank == NODES_PER_RANK_AT_1:
+        scaling, note = "weak", "a rank owns as many nodes as the one GPU of the N=1 line (cfg3, 134 M)"
+    else:
+        scaling, note = "strong", f"fixed {nx}x{ny}x{nz} lattice split over the ranks: {nodes_per_rank / NODES_PER_RANK_AT_1:.3g} of the N=1 line's nodes per rank"
+    label = f"{wname}: {nx}x{ny}x{nz} D3Q27 x{nl} lattices" + (" + spectral Poisson" if nl > 1 else "")
+    if world > 1:
+        pl = f"{planes[0]}" if min(planes) == max(planes) else f"{min(planes)}-{max(planes)}"
+        label += f", z-slabs of {pl} planes over {world} GPUs"
+    if scale_z > 1:
+        label += f" - REHEARSAL: z extent divided by {scale_z}, not the BASELINE size"
+    return {"name": wname, "grid": (nx, ny, nz), "lattices": nl, "in_place": bool(in_place), "scaling": scaling, "scaling_note": note,
+            "nodes_per_rank": int(nodes_per_rank), "planes_per_rank": planes, "label": label, "rehearsal_scale_z": scale_z}
+
+
+def comm_block(raw, steps: int, halo_bytes_formula: int, per_rank_wait=None) -> dict:
+    """The `comm` object of an N>1 (or --force-slab) line from ekpnp_comm_timing_get's sums on rank 0: per exchange kind
+    the bytes a rank sends per step, the time its COMPUTE stream waited for the exchange and the time the exchange took
+    on the comm stream (both HIP events, ms per step); per_rank_wait = total wait per step of every rank."""
+    steps = max(1, steps)
+    out = {"source": "HIP events around the exchanges inside libekpnp.so (ekpnp_comm_timing_get), rank 0",
+           "halo_bytes_per_step": int(raw["halo"]["bytes_sent"]) * (raw["halo"]["n"] // steps if raw["halo"]["n"] else 0),
+           "halo_bytes_per_step_formula": int(halo_bytes_formula)}
+    tw = tt = 0.0
+    for k in ("halo", "edge", "phi"):
+        r = raw[k]
+        out[k] = {"exchanges_per_step": r["n"] / steps, "bytes_sent_per_exchange": int(r["bytes_sent"]),
+                  "wait_ms_per_step": round(r["wait_ms"] / steps, 4), "transfer_ms_per_step": round(r["transfer_ms"] / steps, 4)}
+        tw += r["wait_ms"] / steps
+        tt += r["transfer_ms"] / steps
+    out["wait_ms_per_step"] = round(tw, 4)
+    out["transfer_ms_per_step"] = round(tt, 4)
+    if per_rank_wait is not None:
+        out["wait_ms_per_step_by_rank"] = [round(float(v), 4) for v in per_rank_wait]
+    return out
+
+
+def host_cpu_budget():
+    """(cores the CPU baseline may use, how that was found).  A container's share of the host is its cgroup CPU quota
+    (cpu.max: "<quota> <period>" or "max"), not the affinity mask - the GPU box shows every hardware thread of the
+    host in the mask.  Without a quota: the PHYSICAL cores among the CPUs of the mask."""
+    import math
+
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            if q != "max" and float(per) > 0:
+                return max(1, min(_CPUS_AT_START, math.ceil(float(q) / float(per)))), f"cgroup quota {path}: {q} {per}"
+        except (OSError, ValueError):
+            pass
+    try:  # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            return max(1, min(_CPUS_AT_START, math.ceil(q / per))), f"cgroup v1 quota {q}/{per}"
+    except (OSError, ValueError):
+        pass
+    try:
+        mask = os.sched_getaffinity(0)
+        cores = set()
+        for cpu in mask:
+            base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+            cores.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        if cores:
+            return len(cores), f"no cgroup CPU quota: physical cores among the {len(mask)} CPUs of the affinity mask"
+    except (OSError, AttributeError):
+        pass
+    return max(1, _CPUS_AT_START), "no cgroup CPU quota, no topology: CPUs of the affinity mask"
 
 
 def gouy_chapman_state(sol, p):
@@ -165,9 +295,11 @@ def cpu_baseline(nl: int, budget_s: float = 20.0):
         on ONE core.
     Bounded to about budget_s seconds in total."""
     O = G.load_oracle()
-    # like oracle.host_cores(): OMP_NUM_THREADS if set, else min(16, CPUs of the affinity mask) - the GPU
-    # box grants about 16 cores per GPU while exposing every hardware thread of the host
-    cores = max(1, int(os.environ["OMP_NUM_THREADS"])) if os.environ.get("OMP_NUM_THREADS") else max(1, min(16, _CPUS_AT_START))
+    # OMP_NUM_THREADS if set, else this container's CPU share: its cgroup quota, or the physical cores of its mask
+    if os.environ.get("OMP_NUM_THREADS"):
+        cores, cores_source = max(1, int(os.environ["OMP_NUM_THREADS"])), "OMP_NUM_THREADS"
+    else:
+        cores, cores_source = host_cpu_budget()
     legs = []
     shape = (128, 128, 65)
     p = O.default_params(*shape)
@@ -191,6 +323,7 @@ def cpu_baseline(nl: int, budget_s: float = 20.0):
         "sample": f"{main_leg['workload']}, {k} steps, OpenMP oracle ({dt:.1f} s)",
         "cpu_model": cpu_model(),
         "threads_available": cores,
+        "cores_source": cores_source,
         "cpus_in_affinity_mask": _CPUS_AT_START,
         "pinning": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
         "legs": legs,
@@ -304,7 +437,9 @@ def main():
                          "processes over RCCL's socket transport - functional coverage of the N>1 path, not a bandwidth figure")
     ap.add_argument("--force-slab", action="store_true",
                     help="N=1 only: run the multi-rank code path (split calls, comm stream, RCCL exchanges, the ring closing on the same rank)")
-    ap.add_argument("--dry-run", action="store_true", help="check the launch plumbing only: rendezvous, barrier, one JSON line; no GPU")
+    ap.add_argument("--weak", action="store_true", help="the named grid is ONE RANK's slab; the channel is N of them (the 512^3-per-rank runs of rounds 1-2: --workload cfg3 --weak)")
+    ap.add_argument("--scale-z", type=int, default=1, metavar="D", help="rehearsal: divide the z extent by D (several ranks sharing one GPU); the line says so")
+    ap.add_argument("--dry-run", action="store_true", help="check the launch plumbing only: rendezvous, barrier, one JSON line with the workload that WOULD run; no GPU")
     ap.add_argument("--cpu-baseline-only", type=int, default=None, metavar="LATTICES", help="internal: time the CPU oracle and print its JSON (the child of cpu_baseline_in_child)")
     args = ap.parse_args()
     if args.cpu_baseline_only is not None:
@@ -335,7 +470,10 @@ def main():
         if dist is not None:
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"metric": "MLUPS (full EK-PNP step)", "value": None, "unit": "MLUPS", "n_gpus": world, "dry_run": True}), flush=True)
+            sel = select_workload(args.workload, world, 300 * 10**9, args.in_place, args.weak, args.scale_z)
+            print(json.dumps({"metric": "MLUPS (full EK-PNP step)", "value": None, "unit": "MLUPS", "n_gpus": world, "dry_run": True, "scaling": sel["scaling"],
+                              "config": {"workload": sel["label"], "grid": list(sel["grid"]), "lattices": sel["lattices"], "nodes_per_rank": sel["nodes_per_rank"],
+                                         "planes_per_rank": sel["planes_per_rank"], "scaling_note": sel["scaling_note"]}}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -354,7 +492,17 @@ def main():
     pkg = G.load_package()
 
     free_b, total_b = torch.cuda.mem_get_info()
-    wname, (nx, ny, nz), nl, use_in_place = parse_workload(args.workload, free_b, args.in_place)
+    if args.single_device:
+        free_b //= world  # the ranks share the one device
+    if dist is not None:  # every rank must take the same in-place decision: the smallest free memory counts
+        fb = torch.tensor([free_b], dtype=torch.int64)
+        dist.all_reduce(fb, op=dist.ReduceOp.MIN)
+        free_b = int(fb.item())
+    try:
+        sel = select_workload(args.workload, world, free_b, args.in_place, args.weak, args.scale_z)
+    except ValueError as e:
+        raise SystemExit(f"bench.py: {e}")
+    wname, (nx, ny, nz_global), nl, use_in_place = sel["name"], sel["grid"], sel["lattices"], sel["in_place"]
     slab_path = world > 1 or args.force_slab
     native = slab_path and args.backend == "nccl"
     saved_stdout = None
@@ -364,8 +512,6 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-    nz_global = nz * world  # weak scaling: one cfg-sized slab per GPU
-
     p = pkg.default_params(nx, ny, nz_global)
     p.n_lattices = nl
     if nl < 4:
@@ -482,6 +628,15 @@ def main():
     dt = time.perf_counter() - t0
     n_launch, k_ms, k_nodes = sol.kernel_timing_get()
     n_solves, poisson_ms = sol.phase_timing_get()
+    comm = None
+    if native:
+        raw = sol.comm_timing_get()
+        waits = [sum(r["wait_ms"] for r in raw.values()) / max(1, args.steps)]
+        if dist is not None:
+            allw = [None] * world
+            dist.all_gather_object(allw, waits[0])
+            waits = allw
+        comm = comm_block(raw, args.steps, 2 * 9 * nl * 8 * nx * ny, waits)
     sol.kernel_timing(False)
 
     if dist is not None:
@@ -528,16 +683,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": sel["scaling"],
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{wname}: {nx}x{ny}x{nz_global} D3Q27 x{nl} lattices"
-                + (" + spectral Poisson" if nl > 1 else "")
-                + (f", z-slabs of {nz} planes over {world} GPUs" if world > 1 else "")
-                + (", multi-rank code path on one rank (ring to itself)" if world == 1 and slab_path else ""),
+                "workload": sel["label"] + (", multi-rank code path on one rank (ring to itself)" if world == 1 and slab_path else ""),
                 "grid": [nx, ny, nz_global],
+                "nodes_per_rank": sel["nodes_per_rank"],
+                "planes_per_rank": sel["planes_per_rank"],
+                "scaling_note": sel["scaling_note"],
                 "lattices": nl,
                 "in_place": bool(p.in_place),
                 "transport": transport,
@@ -572,6 +727,9 @@ def main():
                 "avg_launch_ms": round(k_avg_ms, 4),
             },
         }
+        if slab_path:
+            # the scaling loss, itemised: what the compute stream waited for, what the exchanges took, what they moved
+            out["comm"] = comm if comm is not None else {"source": "not measured: the python transport (slab.py) ran, not the library's"}
         if world == 1 and not args.no_cpu_baseline:
             runner.close()
             out["cpu_baseline"] = cpu_baseline_in_child(nl)

@@ -50,6 +50,7 @@ static int fail(Ctx& c, const char* msg) {
 }
 
 namespace ekpnp {
+void set_create_error(const std::string& msg) { g_create_err = msg; }
 void note_launch(Ctx& c, const char* kernel) {
   static const bool debug_sync = std::getenv("EKPNP_DEBUG_SYNC") != nullptr;
   // fault injection for the tests of this very path: EKPNP_INJECT_LAUNCH_FAILURE=<kernel name>
@@ -248,6 +249,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   }
   c.own_stream = true;
   if (hipGetDevice(&c.device) != hipSuccess) { c.err = "hipGetDevice failed"; return bail(EKPNP_ERR_HIP); }
+  c.tri_lds_ok = tridiag_prepare_device();
   if (const char* e = std::getenv("EKPNP_BULK_ZCHUNK")) c.ab_zchunk = std::atoi(e) > 0 ? std::atoi(e) : 0;
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
   if (const char* e = std::getenv("EKPNP_TRI_PARTITION")) c.tri_partition = std::atoi(e) < 0 ? 0 : (std::atoi(e) > 2 ? 2 : std::atoi(e));
@@ -752,13 +754,19 @@ static int collide_range(Ctx& c, int zb, int ze, bool timed) {
   return EKPNP_OK;
 }
 
-// bulk launches of planes [zb, ze) in the z order the in-place shift requires (one launch in A/B mode)
-static void ordered_bulk(Ctx& c, int zb, int ze) {
+// bulk launches of planes [zb, ze) in the z order the in-place shift requires (one launch in A/B mode).
+// lead > 0: the sweep starts with a launch of only `lead` planes (see ekpnp_collide_interior_planes); any launch of
+// at most zchunk planes keeps the in-place invariant (shift >= planes per launch + 1).
+static void ordered_bulk(Ctx& c, int zb, int ze, int lead = 0) {
   if (!c.inplace) { launch_collide_bulk(c, zb, ze); return; }
-  if (c.cur == 0)
+  if (lead > c.zchunk) lead = c.zchunk;
+  if (c.cur == 0) {
+    if (lead > 0 && zb + lead < ze) { launch_collide_bulk(c, zb, zb + lead); zb += lead; }
     for (int z = zb; z < ze; z += c.zchunk) launch_collide_bulk(c, z, z + c.zchunk < ze ? z + c.zchunk : ze);
-  else
+  } else {
+    if (lead > 0 && ze - lead > zb) { launch_collide_bulk(c, ze - lead, ze); ze -= lead; }
     for (int z = ze; z > zb; z -= c.zchunk) launch_collide_bulk(c, z - c.zchunk > zb ? z - c.zchunk : zb, z);
+  }
 }
 
 static void finish_collide(Ctx& c) {
@@ -891,6 +899,7 @@ extern "C" int ekpnp_kernel_timing_enable(ekpnp_ctx* ctx, int enable) {
   c.timing = enable != 0;
   c.ev_used = 0;
   c.evp_used = 0;
+  team_timing_reset(c);
   return EKPNP_OK;
 }
 
@@ -1004,12 +1013,14 @@ extern "C" int ekpnp_collide_interior_planes(ekpnp_ctx* ctx) {
   // profiles/r02_slab_overlap_before.json).  A short lead-in launch drains after ~0.1 ms and lets
   // them in; the rest of the sweep then runs beside the transfer.
   static const int lead_env = std::getenv("EKPNP_SLAB_LEAD_PLANES") ? std::atoi(std::getenv("EKPNP_SLAB_LEAD_PLANES")) : 2;
-  const int lead = (!c.inplace && lead_env > 0 && c.nzl - 2 > 4 * lead_env) ? lead_env : 0;
-  if (lead) {
+  // (in-place slabs sweep in launches of zchunk planes anyway, but the first of them is up to 64 planes = 5 ms
+  // long on cfg3's planes: they get the same short lead-in, at the end of the lattice their ordered sweep starts from)
+  const int lead = (lead_env > 0 && c.nzl - 2 > 4 * lead_env) ? lead_env : 0;
+  if (lead && !c.inplace) {
     launch_collide_bulk(c, 1, 1 + lead);
     launch_collide_bulk(c, 1 + lead, c.nzl - 1);
   } else {
-    ordered_bulk(c, 1, c.nzl - 1);
+    ordered_bulk(c, 1, c.nzl - 1, lead);
   }
   if (stop) {
     HIPCHK(c, hipEventRecord(*stop, c.stream));

@@ -140,6 +140,7 @@ void launch_halo_unpack(Ctx&);
 int build_cprime(Ctx&);  // EKPNP_OK or a status with Ctx::err set
 void launch_poisson_rhs(Ctx&);
 void launch_tridiag(Ctx&);
+bool tridiag_prepare_device();  // per-device function attributes of the partition z solves (current device)
 void launch_phi_efield(Ctx&);
 void launch_slab_thomas_local(Ctx&);
 void launch_slab_reduce_correct(Ctx&);
@@ -219,6 +220,7 @@ struct Ctx {
   int graph_cur = -1;              // value of `cur` the graph was captured at
   bool graph_failed = false;       // capture is not possible here: stay eager
   hipfftHandle plan_fwd = 0, plan_inv = 0;
+  bool tri_lds_ok = false;  // this context's device grants the partition z solves their dynamic LDS (tridiag_prepare_device)
   int tri_partition = 1;  // z solve of a single context: 0 serial sweeps, 1 partition solve on large lattices, 2 wherever it applies
   bool have_fwd = false, have_inv = false;  // each handle is destroyed on its own (a failing second plan must not leak the first)
   bool plans = false;
@@ -249,6 +251,8 @@ void note_launch(Ctx& c, const char* kernel);
 // The status the entry points return after their launches: the recorded launch error (its message
 // names the kernel) or whatever hipGetLastError() holds.  Clears both.
 hipError_t take_launch_error(Ctx& c);
+// the message of a failed call that has no context to hold it (what ekpnp_last_error(NULL) returns)
+void set_create_error(const std::string& msg);
 
 // slab_team.hip: the reference's verbs on a slab context whose team moves the halos itself
 // (ekpnp_slab_attach_comm).  Each returns EKPNP_ERR_INVALID with a message if the context's team
@@ -262,6 +266,8 @@ int team_ctx_reduce(Ctx&, double* value, bool is_max);  // combine a per-slab di
 int team_ctx_turns(Ctx&, int (*fn)(Ctx&, void*), void* arg);  // fn on every slab in rank order (file IO)
 void team_detach(Ctx&);  // called by ekpnp_destroy
 bool team_is_group(const Ctx&);  // the context is a member of an in-process ekpnp_group
+void team_timing_reset(Ctx&);    // ekpnp_kernel_timing_enable: forget the exchanges bracketed so far
+int team_comm_timing_get(Ctx&, int kind, int* n, double* wait_ms, double* transfer_ms, size_t* bytes_sent);
 
 // io.hip pieces shared with slab_team.hip (a slab writes / reads its own planes of a whole-lattice file)
 struct TextIoArgs { const char* path; int append; double time; int first; int kind; };  // kind 0 Tecplot, 1 data_end

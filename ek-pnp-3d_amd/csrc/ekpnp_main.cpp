@@ -30,8 +30,10 @@
 static ekpnp_ctx* ctx = nullptr;
 static ekpnp_group* grp = nullptr;
 
+static bool group_path = false;  // --gpus N / --devices: errors live in the group's slot, also before the group exists
+
 static int fail(const char* what, int rc) {
-  std::fprintf(stderr, "ekpnp_main: %s failed (%d): %s\n", what, rc, grp ? ekpnp_group_last_error(grp) : ekpnp_last_error(ctx));
+  std::fprintf(stderr, "ekpnp_main: %s failed (%d): %s\n", what, rc, group_path ? ekpnp_group_last_error(grp) : ekpnp_last_error(ctx));
   if (grp) ekpnp_group_destroy(grp);
   else if (ctx) ekpnp_destroy(ctx);
   return 1;
@@ -124,6 +126,7 @@ int main(int argc, char* argv[]) {
   std::printf("\n");
 
   if (gpus > 1 || !devices.empty()) {
+    group_path = true;
     int rc = ekpnp_group_create(&P, gpus, devices.empty() ? nullptr : devices.data(), transport, &grp);
     if (rc != EKPNP_OK) return fail("ekpnp_group_create", rc);
   } else {

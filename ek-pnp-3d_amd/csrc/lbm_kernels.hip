@@ -61,9 +61,6 @@ __device__ __forceinline__ double velocity(double rhoinv, double j, double cflin
   return rhoinv * fma(F, hdt, j * cflinv);
 }
 // the body force, LBM.cu:635-637, with its fused multiply-adds written out for the same reason
-
-
-// body force, LBM.cu:635-637
 __device__ __forceinline__ Force body_force(const KArgs& a, double c, double cn, double T, double Ex, double Ey, double Ez) {
   Force F;
   const double q = a.F * (c - cn);

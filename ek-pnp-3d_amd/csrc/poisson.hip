@@ -171,8 +171,14 @@ __global__ void __launch_bounds__(EKPNP_TRI_THREADS) k_tridiag(PArgs a) {
 // image (column index XOR-swizzled by the owning lane: the solve-phase reads are 2-way, the rest
 // conflict-free) and leave the same way.  Same system, different elimination order than k_tridiag:
 // results agree to rounding (tests/test_parity_gpu.py::test_partition_z_solve...).
-// 1/x for the well-scaled pivots of the partition solve (|x| >= 1, finite): hardware reciprocal + two Newton steps
-// (full double precision to an ulp; the IEEE division sequence with its scaling and fix-up costs twice the instructions)
+// 1/x for the pivots of the partition solve: hardware reciprocal + two Newton steps (full double precision to an
+// ulp, not correctly rounded; the IEEE division sequence with its scaling and fix-up costs twice the instructions).
+// Range: the pivots are NORMAL, finite and of one sign.  The local Thomas pivots are |b - c'| >= 1 (b <= -2, 0 >= c' > -1).
+// The interface (Schur) pivots of a low mode b -> -2 start near 2/R and roughly halve at each of the 6 reduction
+// levels (~4e-3 for R = 8), those of a high mode (b = -(2 + dz^2 k^2), up to ~ -1e5 for dz >> dx) stay near |b|; both
+// are far inside the range where v_rcp_f64 needs no scaling (|x| in 2^-1022 .. 2^1022 would do).
+// tests/test_parity_gpu.py::test_partition_z_solve_extreme_anisotropy compares it with the serial IEEE-division
+// sweeps at dz/dx = 1e-3 and 1e3.
 __device__ __forceinline__ double recip(double x) {
 #ifdef EKPNP_TRI_IEEE_DIV
   return 1.0 / x;
@@ -843,24 +849,37 @@ void launch_poisson_rhs(Ctx& c) {
   note_launch(c, "k_poisson_rhs");
 }
 
+// the dynamic-LDS limit of the partition solves is a per-DEVICE function attribute: set when a context is made, on
+// the device it is made on (ekpnp_group_* drives contexts on several devices from one process)
+bool tridiag_prepare_device() {
+  const hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_part<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 8 * 8 * (int)sizeof(double2));
+  const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_part<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 4 * 8 * (int)sizeof(double2));
+  if (e8 != hipSuccess || e4 != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
+}
+
 void launch_tridiag(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
   // c.tri_partition (ekpnp_tune "tri_partition" / EKPNP_TRI_PARTITION): 0 the serial sweeps everywhere (the A/B
   // partner of k_tridiag_part), 1 the partition solve on large lattices, 2 wherever it applies (tests)
-  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_part<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 8 * 8 * (int)sizeof(double2)) == hipSuccess;
-  const bool part = c.tri_partition > 0 && lds_ok && c.nxh % 8 == 0;
+  const bool part = c.tri_partition > 0 && c.tri_lds_ok && c.nxh % 8 == 0;
   const int rows = c.p.nz - 2;
   const bool large = c.tri_partition > 1 || (size_t)nm * (size_t)rows >= (size_t)4 * 1024 * 1024;  // enough modes to fill the chip 8 at a time
-  if (rows <= 64)
+  // every branch notes the kernel it really launched: a rejected launch is reported by that name
+  if (rows <= 64) {
     hipLaunchKernelGGL(k_tridiag_pcr64, dim3((nm + 3) / 4), dim3(256), 0, c.stream, a);
-  else if (part && large && rows <= 256)
+    note_launch(c, "k_tridiag_pcr64");
+  } else if (part && large && rows <= 256) {
     hipLaunchKernelGGL(k_tridiag_part<4>, dim3(nm / 8), dim3(512), 64 * 4 * 8 * sizeof(double2), c.stream, a);
-  else if (part && large && rows <= 512)
+    note_launch(c, "k_tridiag_part<4>");
+  } else if (part && large && rows <= 512) {
     hipLaunchKernelGGL(k_tridiag_part<8>, dim3(nm / 8), dim3(512), 64 * 8 * 8 * sizeof(double2), c.stream, a);
-  else
+    note_launch(c, "k_tridiag_part<8>");
+  } else {
     hipLaunchKernelGGL(k_tridiag, dim3((nm + EKPNP_TRI_THREADS - 1) / EKPNP_TRI_THREADS), dim3(EKPNP_TRI_THREADS), 0, c.stream, a);
-  note_launch(c, "k_tridiag");
+    note_launch(c, "k_tridiag");
+  }
 }
 
 void launch_phi_efield(Ctx& c) {

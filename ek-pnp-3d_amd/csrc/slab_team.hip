@@ -54,16 +54,21 @@ static Rccl* rccl(std::string& err) {
   static std::string why;
   if (!tried) {
     tried = true;
-    // an already loaded librccl.so.1 (e.g. the copy PyTorch-ROCm ships) is reused by soname
-    r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!r.handle) r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // an already loaded librccl.so.1 (e.g. the copy PyTorch-ROCm ships) is reused by soname.
+    // EKPNP_RCCL_LIBRARY names another file to bind (and nothing else is tried then): a site's own build of
+    // RCCL, or - tests/test_capi_cpu.py - a file that does not exist, to see this very failure reported.
+    const char* named = std::getenv("EKPNP_RCCL_LIBRARY");
+    const std::string lib = named && *named ? named : "librccl.so.1";
+    r.handle = dlopen(lib.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!r.handle && !(named && *named)) r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!r.handle) {
-      why = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "?");
+      const char* e = dlerror();  // ONE call: glibc clears the message when it is read
+      why = lib + " cannot be loaded: " + (e ? e : "?");
     } else {
       bool ok = true;
       auto bind = [&](auto& fn, const char* name) {
         fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(r.handle, name));
-        if (!fn) { ok = false; why = std::string("librccl.so.1 lacks ") + name; }
+        if (!fn) { ok = false; why = lib + " lacks " + name; }
       };
       bind(r.GetUniqueId, "ncclGetUniqueId");
       bind(r.CommInitRank, "ncclCommInitRank");
@@ -97,6 +102,14 @@ struct Team {
   std::vector<hipStream_t> cs;                            // comm stream per local slab
   std::vector<hipEvent_t> ready[X_KINDS], done[X_KINDS];  // per local slab
   std::vector<double*> red;                               // 2 doubles of device scratch per local slab
+  // compute streams made with a CU mask (EKPNP_COMM_CUS: some CUs kept free of the slab's own kernels so that the
+  // exchange kernel finds its workgroup slots at once), per local slab, or null
+  std::vector<hipStream_t> masked;
+  // measurement (ekpnp_kernel_timing_enable on the slab): per exchange kind and local slab, timed events around the
+  // transfer on the comm stream and around the compute stream's wait for it
+  struct XEv { hipEvent_t xfer_begin, xfer_end, wait_begin, wait_end; };
+  std::vector<std::vector<XEv>> xev[X_KINDS];
+  std::vector<size_t> xev_used[X_KINDS];
   double t = 0.0;
   std::string err;
 };
@@ -153,6 +166,21 @@ static void for_partners(Team& T, int i, int x, Fn&& fn) {
   }
 }
 
+// the timed events of the next occurrence of exchange x on local slab i (made on first use, reused after a reset)
+static int xev_slot(Team& T, int x, int i, Team::XEv** out) {
+  std::vector<Team::XEv>& v = T.xev[x][i];
+  if (T.xev_used[x][i] == v.size()) {
+    Team::XEv e{};
+    THIP(T, hipEventCreate(&e.xfer_begin));
+    THIP(T, hipEventCreate(&e.xfer_end));
+    THIP(T, hipEventCreate(&e.wait_begin));
+    THIP(T, hipEventCreate(&e.wait_end));
+    v.push_back(e);
+  }
+  *out = &v[T.xev_used[x][i]];
+  return EKPNP_OK;
+}
+
 // start exchange x: everything the slabs have enqueued so far on their compute streams precedes it
 static int exchange_begin(Team& T, int x) {
   const int n = (int)T.m.size();
@@ -168,6 +196,11 @@ static int exchange_begin(Team& T, int x) {
       hipError_t e = hipSuccess;
       for_partners(T, i, x, [&](int j) { if (e == hipSuccess) e = hipStreamWaitEvent(T.cs[i], T.ready[x][j], 0); });
       THIP(T, e);
+    }
+    if (S(T, i).timing) {  // the comm stream gets here when this slab's (and its partners') buffers are ready
+      Team::XEv* ev = nullptr;
+      if ((rc = xev_slot(T, x, i, &ev))) return rc;
+      THIP(T, hipEventRecord(ev->xfer_begin, T.cs[i]));
     }
   }
   if (T.kind == EKPNP_TRANSPORT_RCCL) {
@@ -217,6 +250,7 @@ static int exchange_begin(Team& T, int x) {
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
     THIP(T, hipEventRecord(T.done[x][i], T.cs[i]));
+    if (S(T, i).timing && T.xev_used[x][i] < T.xev[x][i].size()) THIP(T, hipEventRecord(T.xev[x][i][T.xev_used[x][i]].xfer_end, T.cs[i]));
   }
   return EKPNP_OK;
 }
@@ -227,11 +261,19 @@ static int exchange_finish(Team& T, int x) {
   int rc;
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
+    // measurement: the time the compute stream spends between these two events is the time it had nothing to do but
+    // wait for the exchange (0 when the transfer was hidden behind what the stream ran meanwhile)
+    const bool timed = S(T, i).timing && T.xev_used[x][i] < T.xev[x][i].size();
+    if (timed) THIP(T, hipEventRecord(T.xev[x][i][T.xev_used[x][i]].wait_begin, S(T, i).stream));
     THIP(T, hipStreamWaitEvent(S(T, i).stream, T.done[x][i], 0));
     if (T.kind == EKPNP_TRANSPORT_COPY) {
       hipError_t e = hipSuccess;
       for_partners(T, i, x, [&](int j) { if (e == hipSuccess) e = hipStreamWaitEvent(S(T, i).stream, T.done[x][j], 0); });
       THIP(T, e);
+    }
+    if (timed) {
+      THIP(T, hipEventRecord(T.xev[x][i][T.xev_used[x][i]].wait_end, S(T, i).stream));
+      T.xev_used[x][i]++;
     }
   }
   return EKPNP_OK;
@@ -442,15 +484,39 @@ static int team_make_streams(Team& T) {
   const int n = (int)T.m.size();
   T.cs.assign(n, nullptr);
   T.red.assign(n, nullptr);
-  for (int x = 0; x < X_KINDS; ++x) { T.ready[x].assign(n, nullptr); T.done[x].assign(n, nullptr); }
+  T.masked.assign(n, nullptr);
+  for (int x = 0; x < X_KINDS; ++x) {
+    T.ready[x].assign(n, nullptr);
+    T.done[x].assign(n, nullptr);
+    T.xev[x].assign(n, {});
+    T.xev_used[x].assign(n, 0);
+  }
+  // EKPNP_COMM_CUS=<n> (A/B knob, default 0): keep n compute units free of the slab's OWN kernels - its compute
+  // stream is re-made with a CU mask that leaves them out - so that the workgroups of the exchange kernel are placed
+  // the moment it is dispatched instead of competing for wave slots with a sweep of ~10^6 workgroups (the sweep is
+  // bandwidth-bound and does not miss 3 % of the CUs).  KFD deals the mask bits round-robin over the XCDs, so a
+  // multiple of 8 takes the same number of CUs from every XCD and the kernels' bid % 8 XCD maps stay valid.
+  // EKPNP_COMM_CUS_STRICT=1 also confines the comm stream to exactly those CUs.
+  static const int comm_cus = std::getenv("EKPNP_COMM_CUS") ? std::atoi(std::getenv("EKPNP_COMM_CUS")) : 0;
+  static const bool comm_strict = std::getenv("EKPNP_COMM_CUS_STRICT") != nullptr && std::atoi(std::getenv("EKPNP_COMM_CUS_STRICT")) != 0;
   for (int i = 0; i < n; ++i) {
     int rc = use(T, i);
     if (rc) return rc;
     int least = 0, greatest = 0;
     THIP(T, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int ncu = 0;
+    THIP(T, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, S(T, i).device));
+    const bool reserve = comm_cus > 0 && comm_cus < ncu;
+    if (reserve) {
+      std::vector<uint32_t> comp((size_t)(ncu + 31) / 32, 0u), comm(comp.size(), 0u);
+      for (int b = 0; b < ncu; ++b) (b < comm_cus ? comm : comp)[(size_t)b / 32] |= 1u << (b % 32);
+      THIP(T, hipExtStreamCreateWithCUMask(&T.masked[i], (uint32_t)comp.size(), comp.data()));
+      TSLAB(T, i, ekpnp_set_stream(T.m[i], T.masked[i]));  // the slab's kernels and transforms now run beside the reserved CUs
+      if (comm_strict) THIP(T, hipExtStreamCreateWithCUMask(&T.cs[i], (uint32_t)comm.size(), comm.data()));
+    }
     // highest priority: a transfer enqueued behind tens of milliseconds of collision kernels must be
     // dispatched as soon as workgroup slots free up, not after the compute queue has drained
-    THIP(T, hipStreamCreateWithPriority(&T.cs[i], hipStreamNonBlocking, greatest));
+    if (!T.cs[i]) THIP(T, hipStreamCreateWithPriority(&T.cs[i], hipStreamNonBlocking, greatest));
     for (int x = 0; x < X_KINDS; ++x) {
       THIP(T, hipEventCreateWithFlags(&T.ready[x][i], hipEventDisableTiming));
       THIP(T, hipEventCreateWithFlags(&T.done[x][i], hipEventDisableTiming));
@@ -474,13 +540,28 @@ static void team_release(Team& T) {
     for (int x = 0; x < X_KINDS; ++x) {
       if (i < T.ready[x].size() && T.ready[x][i]) (void)hipEventDestroy(T.ready[x][i]);
       if (i < T.done[x].size() && T.done[x][i]) (void)hipEventDestroy(T.done[x][i]);
+      if (i < T.xev[x].size())
+        for (Team::XEv& e : T.xev[x][i]) {
+          (void)hipEventDestroy(e.xfer_begin);
+          (void)hipEventDestroy(e.xfer_end);
+          (void)hipEventDestroy(e.wait_begin);
+          (void)hipEventDestroy(e.wait_end);
+        }
     }
     if (i < T.cs.size() && T.cs[i]) (void)hipStreamDestroy(T.cs[i]);
     if (i < T.red.size() && T.red[i]) (void)hipFree(T.red[i]);
+    if (i < T.masked.size() && T.masked[i]) {
+      // the slab outlives its team (ekpnp_destroy comes after): it gets a plain stream of its own back
+      Ctx& c = S(T, (int)i);
+      hipStream_t plain = nullptr;
+      if (hipStreamCreateWithFlags(&plain, hipStreamNonBlocking) == hipSuccess && ekpnp_set_stream(T.m[i], plain) == EKPNP_OK) c.own_stream = true;
+      (void)hipStreamDestroy(T.masked[i]);
+    }
   }
   T.cs.clear();
   T.red.clear();
-  for (int x = 0; x < X_KINDS; ++x) { T.ready[x].clear(); T.done[x].clear(); }
+  T.masked.clear();
+  for (int x = 0; x < X_KINDS; ++x) { T.ready[x].clear(); T.done[x].clear(); T.xev[x].clear(); T.xev_used[x].clear(); }
 }
 
 // ---- the reference's verbs on ONE attached slab context (one process per GPU) --------------------
@@ -520,6 +601,44 @@ int team_ctx_turns(Ctx& c, int (*fn)(Ctx&, void*), void* arg) { OWN_TEAM(c); ret
 
 bool team_is_group(const Ctx& c) { return c.team && c.team->group; }
 
+void team_timing_reset(Ctx& c) {
+  if (!c.team) return;
+  Team& T = *c.team;
+  for (int x = 0; x < X_KINDS; ++x)
+    if ((size_t)c.team_slot < T.xev_used[x].size()) T.xev_used[x][c.team_slot] = 0;
+}
+
+// sums over the exchanges of kind x bracketed since the last reset, for the slab in slot c.team_slot
+int team_comm_timing_get(Ctx& c, int x, int* n, double* wait_ms, double* transfer_ms, size_t* bytes_sent) {
+  if (!c.team) { c.err = "ekpnp_comm_timing_get: this context has no transport"; return EKPNP_ERR_INVALID; }
+  if (x < 0 || x >= X_KINDS) { c.err = "ekpnp_comm_timing_get: unknown exchange kind"; return EKPNP_ERR_INVALID; }
+  Team& T = *c.team;
+  const int i = c.team_slot;
+  hipError_t e = hipSetDevice(c.device);
+  if (e == hipSuccess) e = hipStreamSynchronize(T.cs[i]);
+  if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+  double w = 0.0, t = 0.0;
+  const size_t used = T.xev_used[x][i];
+  for (size_t k = 0; k < used && e == hipSuccess; ++k) {
+    const Team::XEv& v = T.xev[x][i][k];
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, v.wait_begin, v.wait_end);
+    w += ms;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, v.xfer_begin, v.xfer_end);
+    t += ms;
+  }
+  if (e != hipSuccess) { c.err = std::string("ekpnp_comm_timing_get: ") + hipGetErrorString(e); return EKPNP_ERR_HIP; }
+  if (n) *n = (int)used;
+  if (wait_ms) *wait_ms = w;
+  if (transfer_ms) *transfer_ms = t;
+  if (bytes_sent) {
+    const size_t edge = 4 * (size_t)c.p.ny * c.nxh;
+    *bytes_sent = sizeof(double) * (x == X_HALO ? 2 * c.halo_doubles : x == X_PHI ? 2 * c.plane : edge);
+  }
+  T.xev_used[x][i] = 0;
+  return EKPNP_OK;
+}
+
 void team_detach(Ctx& c) {
   if (!c.team || c.team->group) return;  // a group releases its own team (ekpnp_group_destroy)
   Team* T = c.team;
@@ -534,13 +653,23 @@ using namespace ekpnp;
 
 // ---- C ABI: one process per GPU --------------------------------------------------------------------
 
+// a group call visits several devices; the caller gets its current device back
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+
 extern "C" int ekpnp_comm_unique_id(void* id128) {
   if (!id128) return EKPNP_ERR_INVALID;
+  // no context here: the message goes where ekpnp_create's goes, ekpnp_last_error(NULL)
   std::string err;
   Rccl* nc = rccl(err);
-  if (!nc) return EKPNP_ERR_HIP;
+  if (!nc) { set_create_error("ekpnp_comm_unique_id: " + err); return EKPNP_ERR_HIP; }
   ncclUniqueId id;
-  if (nc->GetUniqueId(&id) != ncclSuccess) return EKPNP_ERR_HIP;
+  const ncclResult_t r = nc->GetUniqueId(&id);
+  if (r != ncclSuccess) { set_create_error(std::string("ncclGetUniqueId: ") + nc->GetErrorString(r)); return EKPNP_ERR_HIP; }
   static_assert(sizeof(id) == EKPNP_UNIQUE_ID_BYTES, "ncclUniqueId size");
   std::memcpy(id128, &id, sizeof id);
   return EKPNP_OK;
@@ -566,12 +695,17 @@ extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
   T->kind = EKPNP_TRANSPORT_RCCL;
   T->nc = nc;
   int rc = team_make_streams(*T);
-  if (rc == EKPNP_OK) {
+  {
+    // ncclCommInitRank is collective: a rank whose local set-up failed still enters it (and destroys the
+    // communicator again below), otherwise its peers would wait in theirs for ever
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     T->comm.assign(1, nullptr);
-    ncclResult_t r = nc->CommInitRank(&T->comm[0], c.nranks, id, c.rank);  // collective over the ranks
-    if (r != ncclSuccess) { T->err = std::string("ncclCommInitRank: ") + nc->GetErrorString(r); T->comm.clear(); rc = EKPNP_ERR_HIP; }
+    ncclResult_t r = nc->CommInitRank(&T->comm[0], c.nranks, id, c.rank);
+    if (r != ncclSuccess) {
+      if (rc == EKPNP_OK) { T->err = std::string("ncclCommInitRank: ") + nc->GetErrorString(r); rc = EKPNP_ERR_HIP; }
+      T->comm.clear();
+    }
   }
   if (rc) {
     c.err = T->err;
@@ -584,14 +718,13 @@ extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
   return EKPNP_OK;
 }
 
-// ---- C ABI: one process, N slabs (ekpnp_main --gpus N) -------------------------------------------
+extern "C" int ekpnp_comm_timing_get(ekpnp_ctx* ctx, int kind, int* n_exchanges, double* wait_ms, double* transfer_ms, size_t* bytes_sent) {
+  if (!ctx) return EKPNP_ERR_INVALID;
+  DeviceGuard device_guard_;
+  return team_comm_timing_get(ctx->c, kind, n_exchanges, wait_ms, transfer_ms, bytes_sent);
+}
 
-// a group call visits several devices; the caller gets its current device back
-struct DeviceGuard {
-  int prev = -1;
-  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
-  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
+// ---- C ABI: one process, N slabs (ekpnp_main --gpus N) -------------------------------------------
 
 struct ekpnp_group {
   Team t;

@@ -150,6 +150,7 @@ def load_library():
         # the library's own halo transport (RCCL / peer copies)
         "ekpnp_comm_unique_id": (i32, [C.c_void_p]),
         "ekpnp_slab_attach_comm": (i32, [ctx, C.c_void_p]),
+        "ekpnp_comm_timing_get": (i32, [ctx, i32, C.POINTER(i32), pd, pd, C.POINTER(sz)]),
         "ekpnp_group_create": (i32, [C.POINTER(Params), i32, C.POINTER(i32), i32, C.POINTER(ctx)]),
         "ekpnp_group_destroy": (i32, [ctx]),
         "ekpnp_group_last_error": (C.c_char_p, [ctx]),
@@ -213,6 +214,18 @@ def comm_unique_id() -> bytes:
     if rc:
         raise EkpnpError(f"ekpnp_comm_unique_id -> {rc} (librccl.so.1 not loadable?)")
     return buf.raw
+
+
+COMM_KINDS = ("halo", "phi", "edge")  # ekpnp_comm_timing_get kinds 0, 1, 2
+
+
+def comm_timing(L, handle, check) -> dict:
+    out = {}
+    for kind, name in enumerate(COMM_KINDS):
+        n, w, t, b = C.c_int(), C.c_double(), C.c_double(), C.c_size_t()
+        check(L.ekpnp_comm_timing_get(handle, kind, C.byref(n), C.byref(w), C.byref(t), C.byref(b)))
+        out[name] = {"n": n.value, "wait_ms": w.value, "transfer_ms": t.value, "bytes_sent": int(b.value)}
+    return out
 
 
 class Solver:
@@ -424,6 +437,11 @@ class Solver:
         self._ck(self._L.ekpnp_kernel_timing_get(self._h, C.byref(n), C.byref(ms), C.byref(nodes)))
         return n.value, ms.value, nodes.value
 
+    def comm_timing_get(self) -> dict:
+        """Per exchange kind of a slab with a transport, since kernel_timing(True): {"halo"|"phi"|"edge":
+        {"n", "wait_ms", "transfer_ms", "bytes_sent"}} - sums over the n exchanges, bytes per exchange."""
+        return comm_timing(self._L, self._h, self._ck)
+
 
 class Group:
     """nslabs z slabs driven by ONE process (ekpnp_group_*): slab i on HIP device devices[i]
@@ -483,6 +501,29 @@ class Group:
 
     def device_bytes(self) -> int:
         return int(self._L.ekpnp_group_device_bytes(self._g))
+
+    # measurement: the hooks are per slab context
+    def kernel_timing(self, enable: bool):
+        for i in range(self.n):
+            self._slab_ck(i, self._L.ekpnp_kernel_timing_enable(self.slab_handle(i), int(enable)))
+
+    def slab_kernel_timing_get(self, i: int):
+        n, ms, nodes = C.c_int(), C.c_double(), C.c_int64()
+        self._slab_ck(i, self._L.ekpnp_kernel_timing_get(self.slab_handle(i), C.byref(n), C.byref(ms), C.byref(nodes)))
+        return n.value, ms.value, nodes.value
+
+    def slab_phase_timing_get(self, i: int):
+        n, ms = C.c_int(), C.c_double()
+        self._slab_ck(i, self._L.ekpnp_phase_timing_get(self.slab_handle(i), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def slab_comm_timing_get(self, i: int) -> dict:
+        h = self.slab_handle(i)
+        return comm_timing(self._L, h, lambda rc: self._slab_ck(i, rc))
+
+    def _slab_ck(self, i: int, rc: int):
+        if rc:
+            raise EkpnpError(f"slab {i}: status {rc}: {self._L.ekpnp_last_error(self.slab_handle(i)).decode()}")
 
     def synchronize(self):
         self._ck(self._L.ekpnp_group_synchronize(self._g))

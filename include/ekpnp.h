@@ -305,8 +305,26 @@ int ekpnp_advance_time(ekpnp_ctx* ctx);
  * ekpnp_record_umax, ekpnp_save_data_tecplot, ekpnp_save_data_end and ekpnp_read_data (ONE
  * whole-lattice file, the ranks take turns in z order) work on the slab context; every rank must
  * make the same calls in the same order.  ekpnp_destroy releases the communicator. */
-int ekpnp_comm_unique_id(void* id128);
+int ekpnp_comm_unique_id(void* id128);  /* on failure the message is in ekpnp_last_error(NULL) */
 int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128);
+/* Failure semantics of the collective calls (no reference counterpart: the reference exit()s on any error,
+ * LBM.cu:35-53).  ekpnp_slab_attach_comm always enters ncclCommInitRank, also on a rank whose local set-up
+ * failed, so its peers return.  Between the turns of the whole-lattice file IO and inside
+ * ekpnp_initialization_converged the ranks agree on a common status.  Everywhere else a rank that returns
+ * a non-OK status from a verb of an attached slab has NOT taken part in that verb's exchanges: its peers
+ * are then waiting inside RCCL, and the host's control plane must end all ranks (as torch.distributed.run
+ * and mpirun do when one rank exits non-zero) - the library cannot recall a collective its peers are in.
+ * EKPNP_RCCL_LIBRARY in the environment names the RCCL library to bind instead of librccl.so.1. */
+
+/* Measurement hook (bench.py's `comm` block; no reference counterpart): while ekpnp_kernel_timing_enable
+ * is on, every exchange of a slab with a transport (attached, or a member of a group: pass the slab's own
+ * context, ekpnp_group_context) is bracketed by HIP events.  kind: 0 the population halo ring, 1 the phi
+ * planes, 2 the all-gather of the Poisson interface coefficients.  Returned and reset: how many exchanges,
+ * the summed time the COMPUTE stream had to wait for them (0 when hidden behind the interior sweep), the
+ * summed time from "buffers ready" to "data landed" on the comm stream, and the bytes this rank sends per
+ * exchange. */
+int ekpnp_comm_timing_get(ekpnp_ctx* ctx, int kind, int* n_exchanges, double* wait_ms,
+                          double* transfer_ms, size_t* bytes_sent);
 
 /* One process, several GPUs (ekpnp_main --gpus N): a group is nslabs slab contexts, slab i on HIP
  * device devices[i] (devices == NULL: i modulo the device count), created, stepped and destroyed

@@ -34,6 +34,70 @@ def test_workload_follows_the_free_memory():
     assert b.parse_workload("512x512x1024", 0, True) == ("512x512x1024", (512, 512, 1024), 4, True)
 
 
+def test_multi_gpu_lines_are_the_baseline_configs_by_name():
+    """`bench.py --gpus N` must run BASELINE.json's configs[3..4]: cfg4 (512x512x1024 split over the ranks) at N = 2
+    and 4, cfg5 (1024^3, 128 planes per rank) at N = 8, and say truthfully whether that is weak or strong scaling
+    against the N=1 line (cfg3, 134 M nodes on the one GPU)."""
+    b = _bench()
+    gb = 10**9
+    one = b.select_workload("auto", 1, 300 * gb)
+    assert one["label"].startswith("cfg3: 512x512x512") and one["scaling"] == "weak" and one["nodes_per_rank"] == 512**3
+    two = b.select_workload("auto", 2, 300 * gb)
+    assert two["label"].startswith("cfg4: 512x512x1024") and two["grid"] == (512, 512, 1024)
+    assert two["planes_per_rank"] == [512, 512] and two["nodes_per_rank"] == 512**3 and two["scaling"] == "weak" and not two["in_place"]
+    four = b.select_workload("auto", 4, 300 * gb)
+    assert four["label"].startswith("cfg4: 512x512x1024") and four["planes_per_rank"] == [256] * 4
+    assert four["nodes_per_rank"] == 512**3 // 2 and four["scaling"] == "strong"
+    eight = b.select_workload("auto", 8, 300 * gb)
+    assert eight["label"].startswith("cfg5: 1024x1024x1024") and eight["planes_per_rank"] == [128] * 8
+    assert eight["nodes_per_rank"] == 512**3 and eight["scaling"] == "weak" and "over 8 GPUs" in eight["label"]
+    # cfg4 by name at N = 8: the strong-scaling end, 128 planes of 512x512 per rank
+    s8 = b.select_workload("cfg4", 8, 300 * gb)
+    assert s8["label"].startswith("cfg4: 512x512x1024") and s8["planes_per_rank"] == [128] * 8 and s8["scaling"] == "strong"
+    assert s8["nodes_per_rank"] == 512**3 // 4
+    # the 512^3-slab-per-rank channel of rounds 1-2 only behind an explicit --weak
+    w4 = b.select_workload("cfg3", 4, 300 * gb, weak=True)
+    assert w4["grid"] == (512, 512, 2048) and w4["scaling"] == "weak" and w4["planes_per_rank"] == [512] * 4
+    # a rehearsal with fewer planes says so and never passes for the BASELINE size
+    r2 = b.select_workload("auto", 2, 300 * gb, scale_z=8)
+    assert r2["grid"] == (512, 512, 128) and "REHEARSAL" in r2["label"] and r2["scaling"] == "strong"
+    # a rank without room for two population buffers makes every rank run in place (free_bytes = minimum over the ranks)
+    assert b.select_workload("auto", 2, 200 * gb)["in_place"] is True
+    # uneven slabs are named as a range; too thin slabs and too many ranks are refused
+    u = b.select_workload("512x512x513", 8, 300 * gb)
+    assert sorted(set(u["planes_per_rank"])) == [64, 65] and "64-65 planes" in u["label"]
+    import pytest
+
+    with pytest.raises(ValueError):
+        b.select_workload("16x16x12", 4, gb)
+    with pytest.raises(ValueError):
+        b.select_workload("cfg5", 17, gb)
+    # device_need_bytes is what capi.hip allocates for cfg3 (DESIGN.md section 3: 232.8 GB populations + fields)
+    assert abs(b.device_need_bytes(512, 512, 512, 4, False) / 1e9 - 250.0) < 2.0
+    assert abs(b.device_need_bytes(512, 512, 512, 4, True) / 1e9 - 148.7) < 2.0
+
+
+def test_comm_block_keys():
+    """what an N>1 line must carry to explain its own scaling loss"""
+    b = _bench()
+    raw = {"halo": {"n": 20, "wait_ms": 4.0, "transfer_ms": 30.0, "bytes_sent": 151_000_000},
+           "edge": {"n": 20, "wait_ms": 10.0, "transfer_ms": 9.0, "bytes_sent": 4_200_000},
+           "phi": {"n": 20, "wait_ms": 2.0, "transfer_ms": 1.0, "bytes_sent": 4_194_304}}
+    c = b.comm_block(raw, 20, 2 * 9 * 4 * 8 * 512 * 512, [0.8, 0.9])
+    assert c["halo_bytes_per_step"] == 151_000_000 and c["halo_bytes_per_step_formula"] == 150_994_944
+    for k in ("halo", "edge", "phi"):
+        assert set(c[k]) == {"exchanges_per_step", "bytes_sent_per_exchange", "wait_ms_per_step", "transfer_ms_per_step"}
+        assert c[k]["exchanges_per_step"] == 1.0
+    assert c["halo"]["wait_ms_per_step"] == 0.2 and c["edge"]["transfer_ms_per_step"] == 0.45
+    assert c["wait_ms_per_step"] == 0.8 and c["transfer_ms_per_step"] == 2.0 and c["wait_ms_per_step_by_rank"] == [0.8, 0.9]
+
+
+def test_cpu_budget_is_read_not_assumed():
+    b = _bench()
+    n, how = b.host_cpu_budget()
+    assert 1 <= n <= (os.cpu_count() or 1) and isinstance(how, str) and how
+
+
 def test_plain_invocation_with_gpus_spawns_its_ranks(tmp_path):
     """`python bench.py --gpus 2` invoked plainly (the way the driver invokes --gpus 1) must start
     its two ranks itself - as child processes, before anything touches a GPU - relay rank 0's one
@@ -50,6 +114,8 @@ def test_plain_invocation_with_gpus_spawns_its_ranks(tmp_path):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["metric"].startswith("MLUPS")
+    # the workload a real run would take: cfg4 by name, 512 planes per rank, weak against the N=1 line
+    assert out["config"]["workload"].startswith("cfg4: 512x512x1024") and out["config"]["planes_per_rank"] == [512, 512] and out["scaling"] == "weak"
 
 
 def test_world_size_must_match_gpus():

@@ -109,3 +109,30 @@ def test_compute_parameters_matches_the_reference_formulas(pkg):
     assert d["C"] == p.chargeinf * p.Lz * p.Lz / (p.voltage * p.eps)
     assert d["Fe"] == p.K * p.voltage / p.diffu
     assert d["Pr"] == p.nu / p.D == 1.0
+
+
+def test_missing_rccl_is_an_error_with_a_message_not_a_crash(tmp_path):
+    """librccl is bound on first use (dlopen).  When it cannot be loaded - EKPNP_RCCL_LIBRARY points the loader at a file
+    that does not exist - ekpnp_comm_unique_id must return EKPNP_ERR_HIP and leave the loader's message in
+    ekpnp_last_error(NULL); the round-2 code read dlerror() twice and built a std::string from NULL.  A child process:
+    the binding is attempted once per process.  No GPU needed."""
+    import subprocess
+    import sys
+
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import __graft_entry__ as G
+pkg = G.load_package()
+L = pkg.load_library()
+buf = C.create_string_buffer(128)
+rc = L.ekpnp_comm_unique_id(buf)
+print("RC", rc, "MSG", L.ekpnp_last_error(None).decode())
+rc2 = L.ekpnp_comm_unique_id(buf)   # asked again: same answer, still no crash
+print("RC2", rc2)
+''' % ROOT
+    env = dict(os.environ, EKPNP_RCCL_LIBRARY=str(tmp_path / "no_such_librccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    assert "RC 2 MSG ekpnp_comm_unique_id:" in r.stdout and "no_such_librccl.so cannot be loaded" in r.stdout, r.stdout
+    assert "RC2 2" in r.stdout

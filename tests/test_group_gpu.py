@@ -439,3 +439,34 @@ print("OK")
         assert (tmp_path / f"one_{name}").read_bytes() == (tmp_path / f"slab_{name}").read_bytes()
     a, b = np.loadtxt(tmp_path / "one_end.dat"), np.loadtxt(tmp_path / "slab_end.dat")
     assert a.shape == b.shape and np.abs(a - b).max() <= 2e-6
+
+
+def test_interior_rank_at_cfg5_width_vs_oracle(pkg, O):
+    """cfg5's planes (1024 x 1024: rows of 16 tiles, 520 half-spectrum columns) in THREE slabs of 4 planes: the middle slab
+    owns no plate - both its z neighbours are other slabs, every row of its z block couples through the interface
+    system, its phi / E kernel takes both halo planes - which is what 6 of the 8 ranks of cfg5 look like.  Against the
+    oracle: Poisson solve, two steps, diagnostics."""
+    po = O.default_params(1024, 1024, 12)
+    po.pb_iterations = 2
+    orc = O.Oracle(po)
+    try:
+        orc.initialization()
+        start = O.perturb_fields(po, orc.fields())
+        orc.set_fields(start)
+        orc.fast_poisson()
+        pois = {k: orc.field(k).copy() for k in ("phi", "Ex", "Ey", "Ez")}
+        orc.init_equilibrium()
+        orc.step(2)
+        want, cur, um = orc.fields(), orc.current(), orc.umax()
+    finally:
+        orc.close()
+    with pkg.Group(_mirror(pkg, po), 3, devices=[0, 0, 0]) as g:
+        assert [g.slab_extent(i) for i in range(3)] == [(0, 4), (4, 4), (8, 4)]
+        g.set_fields(start)
+        g.fast_Poisson()
+        _check(O, {k: g.get_field(k) for k in pois}, pois, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]}, "poisson")
+        g.init_equilibrium()
+        g.step(2)
+        _check(O, g.fields(), want, where="step 2")
+        assert abs(g.current() - cur) <= 1e-8 * abs(cur)
+        assert abs(g.umax() - um) <= 1e-6 * abs(um) + 1e-30

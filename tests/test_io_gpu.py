@@ -278,7 +278,8 @@ import sys, numpy as np
 sys.path.insert(0, %r)
 import __graft_entry__ as G
 pkg = G.load_package()
-p = pkg.default_params(16, 8, 12); p.pb_iterations = 3
+import os
+p = pkg.default_params(16, 8, int(os.environ.get("EKPNP_TEST_NZ", "12"))); p.pb_iterations = 3
 with pkg.Solver(p) as s:
     try:
         s.initialization(); s.init_equilibrium(); s.step(2)
@@ -297,6 +298,10 @@ with pkg.Solver(p) as s:
     assert "ERR" in r.stdout and "kernel k_collide_all" in r.stdout, (r.stdout, r.stderr[-2000:])
     r = run({"EKPNP_INJECT_LAUNCH_FAILURE": "k_collide_bulk", "EKPNP_NO_MERGED_WALLS": "1"}, tmp_path / "x.npy")
     assert "ERR" in r.stdout and "kernel k_collide_bulk" in r.stdout, (r.stdout, r.stderr[-2000:])
+    # the z solve has four kernels; each launch is noted under the name of the kernel that was really launched
+    for nz, knob, kernel in (("12", "1", "k_tridiag_pcr64"), ("300", "2", "k_tridiag_part<8>"), ("131", "2", "k_tridiag_part<4>"), ("300", "0", "k_tridiag")):
+        r = run({"EKPNP_INJECT_LAUNCH_FAILURE": kernel, "EKPNP_TEST_NZ": nz, "EKPNP_TRI_PARTITION": knob}, tmp_path / "x.npy")
+        assert "ERR" in r.stdout and f"kernel {kernel}:" in r.stdout, (kernel, r.stdout, r.stderr[-2000:])
     a = run({}, tmp_path / "a.npy")
     b = run({"EKPNP_DEBUG_SYNC": "1"}, tmp_path / "b.npy")
     assert "OK 0" in a.stdout and "OK 1" in b.stdout, (a.stdout, b.stdout, b.stderr[-2000:])

@@ -101,6 +101,28 @@ def test_slabs_three_lattices(pkg, O):
     assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err
 
 
+def _oracle_from(O, po, st, steps):
+    """the ORACLE (CPU restatement of the reference's step) from the same start fields: fast_Poisson, init_equilibrium, steps"""
+    orc = O.Oracle(po)
+    try:
+        orc.set_fields(st)
+        orc.fast_poisson()
+        orc.init_equilibrium()
+        orc.step(steps)
+        return orc.fields(), orc.current(), orc.umax()
+    finally:
+        orc.close()
+
+
+def _assert_vs_oracle(O, got, oracle_result, ranks):
+    want, cur, um = oracle_result
+    err = O.rel_l2(got, want)
+    assert all(v <= (1e-7 if k == "u" else 1e-9) for k, v in err.items()), ("vs oracle", err)
+    for d in ranks:
+        assert abs(float(d["current"]) - cur) <= 1e-8 * abs(cur)
+        assert abs(float(d["umax"]) - um) <= 1e-6 * abs(um) + 1e-30
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -171,6 +193,7 @@ def test_native_rccl_ranks_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_p
     got = {k: np.concatenate([d[k] for d in parts], axis=0) for k in O.FIELDS}
     err = O.rel_l2(got, want)
     assert all(v < (1e-7 if k == "u" else 1e-11) for k, v in err.items()), err
+    _assert_vs_oracle(O, got, _oracle_from(O, po, st, 6), parts)  # the ranks' result against the ORACLE, not only the HIP single context
     for d in parts:
         assert abs(float(d["current"]) - want_current) <= 1e-9 * abs(want_current)
         assert abs(float(d["umax"]) - want_umax) <= 1e-6 * abs(want_umax) + 1e-30
@@ -221,3 +244,4 @@ def test_native_rccl_two_ranks_full_width_planes(pkg, O, tmp_path):
     for d in parts:
         assert abs(float(d["current"]) - want_current) <= 1e-9 * abs(want_current)
         assert abs(float(d["umax"]) - want_umax) <= 1e-6 * abs(want_umax) + 1e-30
+    _assert_vs_oracle(O, got, _oracle_from(O, po, st, 6), parts)  # 6.3 M nodes x 6 steps on the host cores

@@ -189,20 +189,23 @@ __device__ __forceinline__ double recip(double x) {
   return r;
 #endif
 }
-template <int R>
-__global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
+// The body serves the single context (rows = planes 1 .. NZ-2, zero beyond both ends) and, since round 3, a z slab
+// (rows = the slab's own unknown rows; x just below the first and just above the last row are the interface values
+// `bound` = (g_lo.re, g_lo.im, g_hi.re, g_hi.im)[modes] that k_slab_interface made from the gathered edge values:
+// they move to the right-hand side of the first and the last row).
+template <int R, bool SLAB>
+__device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __restrict__ rows, const int n, const double* __restrict__ bound) {
   extern __shared__ double2 tp_lds[];  // [64 R slots][8 columns]
   const long long ms = (long long)a.ny * a.nxh;
-  const int n = a.nz - 2;
   const long long m0 = (long long)blockIdx.x * 8;
   {
     const int c = threadIdx.x & 7, t = threadIdx.x >> 3;
-    const double2* src = a.spec + m0 + c;
+    const double2* src = rows + m0 + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s = t + 64 * r;
       double2 v = make_double2(0.0, 0.0);
-      if (s < n) v = src[(long long)(s + 1) * ms];
+      if (s < n) v = src[(long long)s * ms];
       tp_lds[s * 8 + (c ^ ((s / R) & 7))] = v;
     }
   }
@@ -216,6 +219,14 @@ __global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
   for (int k = 0; k < R; ++k) {
     const double2 r = mine[k * 8];
     g[k] = make_double2(dz2 * r.x, dz2 * r.y);
+  }
+  if (SLAB) {
+    const double* bw = bound + m0 + w;
+    const double glr = bw[0], gli = bw[ms], ghr = bw[2 * ms], ghi = bw[3 * ms];
+    if (l == 0) g[0] = make_double2(g[0].x - glr, g[0].y - gli);
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+      if (R * l + k == n - 1) g[k] = make_double2(g[k].x - ghr, g[k].y - ghi);
   }
   // interior rows k = 0 .. R-2 of this lane
   double cp[R - 1], v[R - 1], wv[R - 1];
@@ -289,13 +300,24 @@ __global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
   __syncthreads();
   {
     const int c = threadIdx.x & 7, t = threadIdx.x >> 3;
-    double2* dst = a.spec + m0 + c;
+    double2* dst = rows + m0 + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s = t + 64 * r;
-      if (s < n) TRI_STORE(dst + (long long)(s + 1) * ms, tp_lds[s * 8 + (c ^ ((s / R) & 7))]);
+      if (s < n) TRI_STORE(dst + (long long)s * ms, tp_lds[s * 8 + (c ^ ((s / R) & 7))]);
     }
   }
+}
+
+template <int R>
+__global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
+  tridiag_part_body<R, false>(a, a.spec + (long long)a.ny * a.nxh, a.nz - 2, nullptr);
+}
+
+// z slab: the same solve on the slab's m unknown rows (first one on local plane row_a), spectrum read once
+template <int R>
+__global__ void __launch_bounds__(512) k_slab_part(PArgs a, int row_a, int m, const double* __restrict__ bound) {
+  tridiag_part_body<R, true>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound);
 }
 
 // Short channels (NZ - 2 <= 64 unknown rows, e.g. the reference's own 51 planes): the serial
@@ -628,6 +650,66 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __r
   edge[3 * ms + md] = di;
 }
 
+// stage 1 of the read-once slab solve (round 3): ONLY the two edge values, as dot products.  A is symmetric and
+// persymmetric, so  p_1 = e_1^T A^-1 r = u . r  and  p_m = e_m^T A^-1 r = sum_j u_j r_{m+1-j}:  no recurrence, no
+// checkpoint rows, and - u_j decays like lambda^j, lambda = the small root of  lambda^2 + b lambda + 1 = 0  -
+// only the K rows at either end of the block where u_j is not below 2^-66 of u_1 (a term beyond is less than a
+// rounding error of the sum).  The lowest modes (b -> -2, lambda -> 1) need every row, a mid-range mode a few
+// dozen: on a 512-plane slab the kernel touches ~1/6 of the spectrum instead of all of it.  Workgroup = 64 adjacent
+// modes x 4 segments of the K rows (the longest K of the 64 modes), partial sums combined through LDS.
+__global__ void __launch_bounds__(256) k_slab_edges(PArgs a, int row_a, int m, const double* __restrict__ u, double* __restrict__ edge) {
+  __shared__ double part[4][4][64];
+  __shared__ int kmax_s;
+  const int tx = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const long long ms = (long long)a.ny * a.nxh;
+  const long long md = (long long)blockIdx.x * 64 + tx;
+  const bool live = md < ms;
+  int K = 0;
+  if (live) {
+    const double b = mode_diag((int)md, a.ny, a.nxh, a.Lx, a.Ly, a.dz);
+    // lambda = 2 / (-b + sqrt(b^2 - 4)) in (0, 1];  K = rows until lambda^K < 2^-66
+    const double disc = b * b - 4.0;
+    const double lam = 2.0 / (-b + sqrt(disc > 0.0 ? disc : 0.0));
+    const double nl = -log(lam);
+    K = (nl * (double)m > 45.75) ? (int)(45.75 / nl) + 1 : m;
+    if (K > m) K = m;
+  }
+  if (threadIdx.x == 0) kmax_s = 0;
+  __syncthreads();
+  {  // wave maximum, then one atomic per wave
+    int kw = K;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kw = max(kw, __shfl_xor(kw, o, 64));
+    if (tx == 0) atomicMax(&kmax_s, kw);
+  }
+  __syncthreads();
+  const int kmax = kmax_s;
+  const int chunk = (kmax + 3) / 4;
+  const int j0 = seg * chunk + 1, j1 = min(j0 + chunk - 1, K);  // this thread's rows j0 .. j1 of 1 .. K (its own K)
+  double p1r = 0.0, p1i = 0.0, pmr = 0.0, pmi = 0.0;
+  if (live) {
+    const double2* s = a.spec + md + (long long)row_a * ms;
+    const double* up = u + md;
+#pragma unroll 4
+    for (int j = j0; j <= j1; ++j) {
+      const double uj = up[(long long)(j - 1) * ms];
+      const double2 lo = s[(long long)(j - 1) * ms];
+      const double2 hi = s[(long long)(m - j) * ms];
+      p1r = fma(uj, lo.x, p1r);
+      p1i = fma(uj, lo.y, p1i);
+      pmr = fma(uj, hi.x, pmr);
+      pmi = fma(uj, hi.y, pmi);
+    }
+  }
+  part[seg][0][tx] = p1r; part[seg][1][tx] = p1i; part[seg][2][tx] = pmr; part[seg][3][tx] = pmi;
+  __syncthreads();
+  if (seg == 0 && live) {
+    const double dz2 = a.dz * a.dz;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) edge[(long long)q * ms + md] = dz2 * (((part[0][q][tx] + part[1][q][tx]) + part[2][q][tx]) + part[3][q][tx]);
+  }
+}
+
 // stage 2: interface system (block tridiagonal, 2x2 blocks, P-1 interfaces) + back substitution.
 // Interface i sits between slab i and i+1: X_i = x_last(slab i), Y_i = x_first(slab i+1):
 //   um_i X_{i-1} + X_i + u1_i Y_i             = p_last(i)
@@ -820,9 +902,19 @@ int build_cprime(Ctx& c) {
   return EKPNP_OK;
 }
 
+// Slabs of up to 512 unknown rows take the read-once pair (k_slab_edges + k_slab_part: the spectrum is read once for
+// the solve, plus the few rows at either end of the block for the edge values); taller slabs and
+// ekpnp_tune(ctx, "tri_partition", 0) (the A/B partner) keep the serial pair k_slab_thomas_local + k_slab_reduce_correct.
+static inline bool slab_read_once(const Ctx& c) { return c.tri_partition > 0 && c.tri_lds_ok && c.nxh % 8 == 0 && c.slab_m >= 1 && c.slab_m <= 512; }
+
 void launch_slab_thomas_local(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
+  if (slab_read_once(c)) {
+    hipLaunchKernelGGL(k_slab_edges, dim3((nm + 63) / 64), dim3(256), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, c.edge_local);
+    note_launch(c, "k_slab_edges");
+    return;
+  }
   hipLaunchKernelGGL(k_slab_thomas_local, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, c.edge_local);
   note_launch(c, "k_slab_thomas_local");
 }
@@ -833,6 +925,20 @@ void launch_slab_reduce_correct(Ctx& c) {
   // the edge buffer of this rank has been gathered and is free again: it takes (g_lo, g_hi)
   hipLaunchKernelGGL(k_slab_interface, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.edge_all, c.u1um, c.edge_local);
   note_launch(c, "k_slab_interface");
+  if (slab_read_once(c)) {
+    const int m = c.slab_m;
+    if (m <= 128) {
+      hipLaunchKernelGGL(k_slab_part<2>, dim3(nm / 8), dim3(512), 64 * 2 * 8 * sizeof(double2), c.stream, a, c.slab_row_a, m, c.edge_local);
+      note_launch(c, "k_slab_part<2>");
+    } else if (m <= 256) {
+      hipLaunchKernelGGL(k_slab_part<4>, dim3(nm / 8), dim3(512), 64 * 4 * 8 * sizeof(double2), c.stream, a, c.slab_row_a, m, c.edge_local);
+      note_launch(c, "k_slab_part<4>");
+    } else {
+      hipLaunchKernelGGL(k_slab_part<8>, dim3(nm / 8), dim3(512), 64 * 8 * 8 * sizeof(double2), c.stream, a, c.slab_row_a, m, c.edge_local);
+      note_launch(c, "k_slab_part<8>");
+    }
+    return;
+  }
   hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.edge_local, c.slab_w);
   note_launch(c, "k_slab_reduce_correct");
 }
@@ -854,7 +960,10 @@ void launch_poisson_rhs(Ctx& c) {
 bool tridiag_prepare_device() {
   const hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_part<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 8 * 8 * (int)sizeof(double2));
   const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_part<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 4 * 8 * (int)sizeof(double2));
-  if (e8 != hipSuccess || e4 != hipSuccess) { (void)hipGetLastError(); return false; }
+  const hipError_t s8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_part<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 8 * 8 * (int)sizeof(double2));
+  const hipError_t s4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_part<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 4 * 8 * (int)sizeof(double2));
+  const hipError_t s2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_part<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 2 * 8 * (int)sizeof(double2));
+  if (e8 != hipSuccess || e4 != hipSuccess || s8 != hipSuccess || s4 != hipSuccess || s2 != hipSuccess) { (void)hipGetLastError(); return false; }
   return true;
 }
 

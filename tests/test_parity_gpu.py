@@ -820,4 +820,6 @@ def test_partition_z_solve_extreme_anisotropy(pkg, O, dz):
                 out.append({k: s.get_field(k) for k in ("phi", "Ex", "Ey", "Ez")})
         assert all(np.isfinite(v).all() for v in out[1].values())
         err = O.rel_l2(out[1], out[0], {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
-        assert err["phi"] < 1e-11 and err["E"] < 1e-9, (shape, dz, err)
+        # E is the central difference of the returned phi in both runs (bit for bit, K4): at dz = 1e-11 neighbouring planes
+        # differ by ~1e-6 of phi, so phi's 4e-14 shows as ~1e-8 of Ez - the check of the solve is phi
+        assert err["phi"] < 1e-11 and err["E"] < (1e-9 if dz > 1e-9 else 1e-6), (shape, dz, err)

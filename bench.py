@@ -541,6 +541,7 @@ def main():
         prof, ic_note = pb_profile_from_product(pkg, p)  # before the big allocation, on this rank's own GPU
 
     err, runner, sol = None, None, None
+    fell_back = False  # True: the library's own RCCL transport could not be set up and slab.py's moved the halos instead
     try:
         if not slab_path:
             sol = runner = pkg.Solver(p)
@@ -601,6 +602,7 @@ def main():
             runner = DistributedSlab(p, rank, world, dist, group=data_group)
             sol = runner.solver
             native = False
+            fell_back = True
             transport = "torch.distributed RCCL process group (fallback: in-library communicator failed)"
 
     if prof is not None:
@@ -688,7 +690,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": sel["label"] + (", multi-rank code path on one rank (ring to itself)" if world == 1 and slab_path else ""),
+                "workload": sel["label"] + (", multi-rank code path on one rank (ring to itself)" if world == 1 and slab_path else "")
+                + (" - FALLBACK TRANSPORT (torch.distributed, not the library's)" if fell_back else ""),
                 "grid": [nx, ny, nz_global],
                 "nodes_per_rank": sel["nodes_per_rank"],
                 "planes_per_rank": sel["planes_per_rank"],
@@ -728,6 +731,8 @@ def main():
             },
         }
         if slab_path:
+            # a line measured on the python safety-net transport must not pass for the library's: said at the top level
+            out["transport_fallback"] = fell_back
             # the scaling loss, itemised: what the compute stream waited for, what the exchanges took, what they moved
             out["comm"] = comm if comm is not None else {"source": "not measured: the python transport (slab.py) ran, not the library's"}
         if world == 1 and not args.no_cpu_baseline:

@@ -32,6 +32,11 @@ def start(run, p, shape_of):
     run.set_field("cn", col(p.chargeinf * np.exp(phi / vt)))
     run.set_field("rho", col(np.full(nz, p.rho0)))
     run.set_field("T", col(p.TH * (p.Lz - p.dz * z) / p.Lz))
+    import bench
+
+    if not hasattr(run, "z0"):
+        run.z0 = 0  # a group speaks whole-lattice arrays
+    bench.apply_perturbation(run, None, p)  # x-y-z dependent start: the two shapes are compared field by field below
     run.fast_Poisson()
     run.init_equilibrium()
 
@@ -59,10 +64,18 @@ def main():
     with pkg.Solver(p) as s:
         start(s, p, s.shape)
         enq, ms = measure(s, steps)
+        ref = {k: s.get_field(k) for k in ("rho", "c", "phi", "ux", "uz", "T")}
         out["one_context"] = {"host_enqueue_ms_per_step": round(enq, 3), "ms_per_step": round(ms, 3), "MLUPS": round(nx * ny * nz / ms / 1e3, 1)}
     with pkg.Group(p, nslabs, devices=[0] * nslabs) as g:
         start(g, p, g.shape)
         enq, ms = measure(g, steps)
+        # the decomposition at full plane width against the single context, field by field (same start, same number of steps)
+        err = {}
+        for k, want in ref.items():
+            got = g.get_field(k)
+            err[k] = float(np.sqrt(((got - want) ** 2).sum() / (want**2).sum()))
+            del got
+        out["group_vs_one_context_rel_l2"] = err
         out["group"] = {"host_enqueue_ms_per_step": round(enq, 3), "ms_per_step": round(ms, 3), "MLUPS": round(nx * ny * nz / ms / 1e3, 1),
                         "device_ms_per_slab_step": round(ms / nslabs, 3)}
     out["group_over_one_context"] = round(out["group"]["ms_per_step"] / out["one_context"]["ms_per_step"], 4)

@@ -656,9 +656,10 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __r
 // only the K rows at either end of the block where u_j is not below 2^-66 of u_1 (a term beyond is less than a
 // rounding error of the sum).  The lowest modes (b -> -2, lambda -> 1) need every row, a mid-range mode a few
 // dozen: on a 512-plane slab the kernel touches ~1/6 of the spectrum instead of all of it.  Workgroup = 64 adjacent
-// modes x 4 segments of the K rows (the longest K of the 64 modes), partial sums combined through LDS.
-__global__ void __launch_bounds__(256) k_slab_edges(PArgs a, int row_a, int m, const double* __restrict__ u, double* __restrict__ edge) {
-  __shared__ double part[4][4][64];
+// modes x EDGE_SEGS segments of the K rows (the longest K of the 64 modes), partial sums combined through LDS.
+constexpr int EDGE_SEGS = 16;  // 4 measured first: 0.133 ms on a 512-plane slab, the low modes' 128 dependent rows per thread being the critical path
+__global__ void __launch_bounds__(64 * EDGE_SEGS) k_slab_edges(PArgs a, int row_a, int m, const double* __restrict__ u, double* __restrict__ edge) {
+  __shared__ double part[EDGE_SEGS][4][64];
   __shared__ int kmax_s;
   const int tx = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const long long ms = (long long)a.ny * a.nxh;
@@ -676,15 +677,15 @@ __global__ void __launch_bounds__(256) k_slab_edges(PArgs a, int row_a, int m, c
   }
   if (threadIdx.x == 0) kmax_s = 0;
   __syncthreads();
-  {  // wave maximum, then one atomic per wave
+  if (seg == 0) {  // the 64 modes of the workgroup are the lanes of its first wave
     int kw = K;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) kw = max(kw, __shfl_xor(kw, o, 64));
-    if (tx == 0) atomicMax(&kmax_s, kw);
+    if (tx == 0) kmax_s = kw;
   }
   __syncthreads();
   const int kmax = kmax_s;
-  const int chunk = (kmax + 3) / 4;
+  const int chunk = (kmax + EDGE_SEGS - 1) / EDGE_SEGS;
   const int j0 = seg * chunk + 1, j1 = min(j0 + chunk - 1, K);  // this thread's rows j0 .. j1 of 1 .. K (its own K)
   double p1r = 0.0, p1i = 0.0, pmr = 0.0, pmi = 0.0;
   if (live) {
@@ -703,10 +704,12 @@ __global__ void __launch_bounds__(256) k_slab_edges(PArgs a, int row_a, int m, c
   }
   part[seg][0][tx] = p1r; part[seg][1][tx] = p1i; part[seg][2][tx] = pmr; part[seg][3][tx] = pmi;
   __syncthreads();
-  if (seg == 0 && live) {
+  if (seg < 4 && live) {  // wave q sums quantity q over the segments, in segment order
     const double dz2 = a.dz * a.dz;
+    double acc = part[0][seg][tx];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) edge[(long long)q * ms + md] = dz2 * (((part[0][q][tx] + part[1][q][tx]) + part[2][q][tx]) + part[3][q][tx]);
+    for (int g = 1; g < EDGE_SEGS; ++g) acc += part[g][seg][tx];
+    edge[(long long)seg * ms + md] = dz2 * acc;
   }
 }
 
@@ -911,7 +914,7 @@ void launch_slab_thomas_local(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
   if (slab_read_once(c)) {
-    hipLaunchKernelGGL(k_slab_edges, dim3((nm + 63) / 64), dim3(256), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, c.edge_local);
+    hipLaunchKernelGGL(k_slab_edges, dim3((nm + 63) / 64), dim3(64 * EDGE_SEGS), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, c.edge_local);
     note_launch(c, "k_slab_edges");
     return;
   }

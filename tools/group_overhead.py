@@ -53,14 +53,21 @@ def measure(run, steps):
 
 
 def main():
-    grid = sys.argv[1] if len(sys.argv) > 1 else "512x512x768"
-    nslabs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    grid = pos[0] if len(pos) > 0 else "512x512x768"
+    nslabs = int(pos[1]) if len(pos) > 1 else 8
+    steps = int(pos[2]) if len(pos) > 2 else 20
     nx, ny, nz = (int(v) for v in grid.split("x"))
     pkg = G.load_package()
     p = pkg.default_params(nx, ny, nz)
     p.in_place = 1
     out = {"grid": [nx, ny, nz], "nslabs": nslabs, "steps": steps}
+    if "--group-only" in sys.argv:  # under rocprofv3 --kernel-trace: tools/gpu_busy_from_trace.py reads the device's idle time off the trace
+        with pkg.Group(p, nslabs, devices=[0] * nslabs) as g:
+            start(g, p, g.shape)
+            enq, ms = measure(g, steps)
+            print(json.dumps({"group": {"host_enqueue_ms_per_step": round(enq, 3), "ms_per_step": round(ms, 3)}}))
+        return
     with pkg.Solver(p) as s:
         start(s, p, s.shape)
         enq, ms = measure(s, steps)

@@ -470,3 +470,35 @@ def test_interior_rank_at_cfg5_width_vs_oracle(pkg, O):
         _check(O, g.fields(), want, where="step 2")
         assert abs(g.current() - cur) <= 1e-8 * abs(cur)
         assert abs(g.umax() - um) <= 1e-6 * abs(um) + 1e-30
+
+
+def test_cfg4_planes_decomposed_over_8_slabs_equal_one_context(pkg, O):
+    """cfg4's full 512 x 512 planes as a DECOMPOSITION at (nearly) full height: 512 x 512 x 768 in 8 in-place slabs of 96
+    planes next to each other on the one GPU (201 M nodes, the most that fits beside the halo buffers; cfg4@8's slabs have
+    128 planes) against the same lattice in ONE in-place context - same perturbed x-y-z dependent start, 5 steps.  The
+    single context itself is pinned to the oracle at this width by test_full_size_vs_oracle[cfg3_width]."""
+    import importlib.util
+    import torch
+
+    if torch.cuda.mem_get_info()[0] < 285 * 10**9:
+        pytest.skip("needs 285 GB of free device memory")
+    spec = importlib.util.spec_from_file_location("group_overhead", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "group_overhead.py"))
+    go = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(go)
+    p = pkg.default_params(512, 512, 768)
+    p.in_place = 1
+    keys = ("rho", "c", "cn", "phi", "T", "ux", "uy", "uz", "Ez")
+    with pkg.Solver(p) as s:
+        go.start(s, p, s.shape)
+        s.step(5)
+        want = {k: s.get_field(k) for k in keys}
+        cur = s.current()
+    with pkg.Group(p, 8, devices=[0] * 8) as g:
+        go.start(g, p, g.shape)
+        g.step(5)
+        for k in keys:
+            got = g.get_field(k)
+            err = float(np.sqrt(((got - want[k]) ** 2).sum() / (want[k] ** 2).sum()))
+            assert err <= (1e-7 if k in ("ux", "uy", "uz") else 1e-9), (k, err)
+            del got
+        assert abs(g.current() - cur) <= 1e-8 * abs(cur)

@@ -309,8 +309,9 @@ int ekpnp_comm_unique_id(void* id128);  /* on failure the message is in ekpnp_la
 int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128);
 /* Failure semantics of the collective calls (no reference counterpart: the reference exit()s on any error,
  * LBM.cu:35-53).  ekpnp_slab_attach_comm always enters ncclCommInitRank, also on a rank whose local set-up
- * failed, so its peers return.  Between the turns of the whole-lattice file IO and inside
- * ekpnp_initialization_converged the ranks agree on a common status.  Everywhere else a rank that returns
+ * failed, so its peers return.  Between the turns of the whole-lattice file IO the ranks agree on a common
+ * status (a file one rank cannot open fails the call on every rank), and the residual / NaN test of
+ * ekpnp_initialization_converged is a maximum over the ranks (all stop in the same sweep).  Everywhere else a rank that returns
  * a non-OK status from a verb of an attached slab has NOT taken part in that verb's exchanges: its peers
  * are then waiting inside RCCL, and the host's control plane must end all ranks (as torch.distributed.run
  * and mpirun do when one rank exits non-zero) - the library cannot recall a collective its peers are in.

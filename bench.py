@@ -703,6 +703,8 @@ def main():
                 "b_alg_step_bytes_per_node": b_alg_step(nl),
                 "step_roofline_frac": round(b_alg_step(nl) * mlups / world * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
                 "device_bytes": sol.device_bytes(),
+                # arenas the context timed at creation and the one it kept (tried 0: the arena is most of the device - cfg3, cfg5)
+                "placement": sol.placement_report(),
                 "finite": finite,
                 # HIP events on the context's stream inside the timed region: the collide sweep of the interior
                 # planes, the Poisson solve (on slabs: stage 1 to stage 3, exchanges included), and what is

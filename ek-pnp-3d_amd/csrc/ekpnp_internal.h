@@ -183,6 +183,8 @@ struct Ctx {
     if (!inplace) return pop[cur ^ 1][l];
     return pop[0][l] ? pop[0][l] + (size_t)(cur == 0 ? 0 : shift) * pplane : nullptr;
   }
+  int placement_tries = 0, placement_chosen = 0;  // placement_search (capi.hip): arenas timed at creation, the one kept
+  double placement_ms[8] = {};                    // their best sweep times
   bool rhs_ready = false;      // work[] holds the Poisson rhs of the current c, cn (written by the collide)
   bool streamed_state = true;  // true: pop[cur] holds X1 (post-stream, e.g. fresh equilibrium);
                                // false: pop[cur] holds post-collision populations (pull next)

@@ -112,6 +112,7 @@ def load_library():
         "ekpnp_kernel_timing_get": (i32, [ctx, C.POINTER(i32), pd, C.POINTER(C.c_int64)]),
         "ekpnp_phase_timing_get": (i32, [ctx, C.POINTER(i32), pd]),
         "ekpnp_device_bytes": (sz, [ctx]),
+        "ekpnp_placement_report": (i32, [ctx, C.POINTER(i32), C.POINTER(i32), pd, i32]),
         "ekpnp_graph_state": (i32, [ctx]),
         "ekpnp_debug_sync_enabled": (i32, []),
         "ekpnp_tune": (i32, [ctx, C.c_char_p, i32]),
@@ -290,6 +291,12 @@ class Solver:
 
     def device_bytes(self) -> int:
         return int(self._L.ekpnp_device_bytes(self._h))
+
+    def placement_report(self) -> dict:
+        """{"tried": n, "chosen": i, "sweep_ms": [...]}: the arenas ekpnp_create timed and the one it kept (tried == 0: no search)"""
+        n, ch, ms = C.c_int(), C.c_int(), (C.c_double * 8)()
+        self._ck(self._L.ekpnp_placement_report(self._h, C.byref(n), C.byref(ch), ms, 8))
+        return {"tried": n.value, "chosen": ch.value, "sweep_ms": [round(ms[k], 4) for k in range(n.value)]}
 
     def copy_bandwidth(self, nbytes: int = 1 << 32) -> float:
         """GB/s (read + write) of a plain contiguous device copy: the measured streaming ceiling."""

@@ -229,6 +229,12 @@ int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* total_ms,
  * including the exchanges in between) is bracketed the same way; this returns and resets the sum. */
 int ekpnp_phase_timing_get(ekpnp_ctx* ctx, int* n_solves, double* poisson_ms);
 size_t ekpnp_device_bytes(const ekpnp_ctx* ctx);
+/* Placement search (no reference counterpart).  On lattices that fill only part of the device the speed of the sweep
+ * depends on where the population arena lies in HBM (up to 13 % between placements of the same context); when there is
+ * room, ekpnp_create / ekpnp_create_slab time the real sweep on up to EKPNP_PLACEMENT_TRIES (environment, default 3,
+ * 1 = off) arenas and keep the fastest.  This reports how many were tried, which one was kept and their sweep times
+ * in ms (n_tried == 0: no search - the arena is most of the device, or the lattice is launch-bound). */
+int ekpnp_placement_report(ekpnp_ctx* ctx, int* n_tried, int* chosen, double* sweep_ms, int capacity);
 /* Streaming-copy rate of this device in GB/s (read + write bytes / time) of a plain contiguous
  * copy of `bytes` bytes on the context's stream: the secondary denominator SURVEY.md 8(d) asks
  * for next to the 8 TB/s spec figure.  Allocates and frees 2 x `bytes` of scratch. */

@@ -9,12 +9,17 @@ import bench
 
 pkg = G.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-p = pkg.default_params(512, 512, 512)
+grid = tuple(int(v) for v in sys.argv[3].split("x")) if len(sys.argv) > 3 else (512, 512, 512)  # round 3: thin lattices too
+p = pkg.default_params(*grid)
 if len(sys.argv) > 2:
     p.in_place = int(sys.argv[2])
 prof, _ = bench.pb_profile_from_product(pkg, p)
+hold = []  # EKPNP_SPREAD_HOLD=<GB>: a dummy allocation of that size made before every context, so that the next arena lands elsewhere
 out = []
+import torch
 for k in range(n):
+    if os.environ.get("EKPNP_SPREAD_HOLD"):
+        hold.append(torch.empty(int(float(os.environ["EKPNP_SPREAD_HOLD"]) * 2**30), dtype=torch.uint8, device="cuda"))
     s = pkg.Solver(p)
     bench.product_pb_state(s, p, prof)
     s.fast_Poisson(); s.init_equilibrium(); s.step(8); s.synchronize()
@@ -22,7 +27,7 @@ for k in range(n):
     t0 = time.perf_counter(); s.step(25); s.synchronize(); dt = time.perf_counter() - t0
     _, ms, _ = s.kernel_timing_get()
     ptrs = [s.field_device_ptr(f) for f in ("rho", "Ex", "T")]
-    print(f"context {k}: {dt / 25 * 1e3:8.3f} ms/step, bulk {ms / 25:8.3f} ms, {512**3 * 25 / dt / 1e6:8.1f} MLUPS, rho @ {ptrs[0]:#x}", flush=True)
+    print(f"context {k}: {dt / 25 * 1e3:8.3f} ms/step, bulk {ms / 25:8.3f} ms, {grid[0] * grid[1] * grid[2] * 25 / dt / 1e6:8.1f} MLUPS, rho @ {ptrs[0]:#x}, placement {s.placement_report()}", flush=True)
     out.append(dt / 25 * 1e3)
     s.close()
 a = np.array(out)

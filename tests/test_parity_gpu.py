@@ -823,3 +823,37 @@ def test_partition_z_solve_extreme_anisotropy(pkg, O, dz):
         # E is the central difference of the returned phi in both runs (bit for bit, K4): at dz = 1e-11 neighbouring planes
         # differ by ~1e-6 of phi, so phi's 4e-14 shows as ~1e-8 of Ez - the check of the solve is phi
         assert err["phi"] < 1e-11 and err["E"] < (1e-9 if dz > 1e-9 else 1e-6), (shape, dz, err)
+
+
+def test_placement_search_changes_no_bit(pkg, O, tmp_path):
+    """ekpnp_create times the real sweep on up to three population arenas and keeps the fastest (capi.hip placement_search).
+    Which arena is kept must not change a single bit of the results, and the probe sweeps must leave no trace (they run on
+    an all-zero lattice and write NaN moments): the same run with EKPNP_PLACEMENT_TRIES=1 (no search) in another process
+    gives identical fields.  512 x 128 x 80: 5.2 M nodes, above the 4 M-node threshold of the search."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as G
+pkg = G.load_package()
+p = pkg.default_params(512, 128, 80); p.pb_iterations = 3
+p.in_place = int(sys.argv[2])
+with pkg.Solver(p) as s:
+    rep = s.placement_report()
+    s.initialization(); s.init_equilibrium(); s.step(3)
+    np.savez(sys.argv[1], **s.fields())
+print("REPORT", json.dumps(rep))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for in_place in ("0", "1"):
+        outs = []
+        for tries in ("3", "1"):
+            out = tmp_path / f"f_{in_place}_{tries}.npz"
+            r = subprocess.run([sys.executable, "-c", code, str(out), in_place], env=dict(os.environ, EKPNP_PLACEMENT_TRIES=tries), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            rep = json.loads(r.stdout.split("REPORT", 1)[1])
+            assert rep["tried"] == (3 if tries == "3" else 0) and (tries == "1" or all(v > 0 for v in rep["sweep_ms"])), rep
+            outs.append(np.load(out))
+        for k in outs[0].files:
+            assert np.isfinite(outs[0][k]).all() and np.array_equal(outs[0][k], outs[1][k]), (in_place, k)

@@ -371,7 +371,10 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   // into the phi array
   c.fft_z0 = (c.z0 == 0) ? 1 : 0;
   c.fft_nz = c.nzl - c.fft_z0 - ((c.z0 + c.nzl == p->nz) ? 1 : 0);
-  {
+  // planes of 1024 x 1024 (cfg5) are transformed by the library's own row and column kernels (fft_plane.h: 2 + 2 kernels
+  // per solve where rocFFT takes 4 + 4); everything else by rocFFT plans
+  if ((rc = plane_fft_setup(c))) return bail(rc);
+  if (!c.own_fft) {
     int n[2] = {p->ny, p->nx};
     int rembed[2] = {p->ny, p->nx};      // real planes, dense
     int cembed[2] = {p->ny, c.nxh};      // half spectrum with the padded row pitch
@@ -431,6 +434,7 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
     if (c.halo[k]) (void)hipFree(c.halo[k]);
     if (c.phi_halo[k]) (void)hipFree(c.phi_halo[k]);
   }
+  if (c.fft_tw) (void)hipFree(c.fft_tw);
   if (c.have_fwd) hipfftDestroy(c.plan_fwd);
   if (c.have_inv) hipfftDestroy(c.plan_inv);
   for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -448,8 +452,8 @@ extern "C" int ekpnp_set_stream(ekpnp_ctx* ctx, void* s) {
   if (c.own_stream) { (void)hipStreamDestroy(c.stream); c.own_stream = false; }
   drop_graph(c);
   c.stream = (hipStream_t)s;
-  FFTCHK(c, hipfftSetStream(c.plan_fwd, c.stream));
-  FFTCHK(c, hipfftSetStream(c.plan_inv, c.stream));
+  if (c.have_fwd) FFTCHK(c, hipfftSetStream(c.plan_fwd, c.stream));
+  if (c.have_inv) FFTCHK(c, hipfftSetStream(c.plan_inv, c.stream));
   return EKPNP_OK;
 }
 
@@ -584,9 +588,9 @@ static int poisson_single(Ctx& c) {
   if (trc) return trc;
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
-  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec()));
+  if (int frc = plane_fft_forward(c)) return frc;
   launch_tridiag(c);
-  FFTCHK(c, hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out()));
+  if (int frc = plane_fft_inverse(c)) return frc;
   launch_phi_efield(c);
   LAUNCHCHK(c);
   return poisson_timing_mark(c, false);
@@ -1159,7 +1163,7 @@ extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
   }
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
-  FFTCHK(c, hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec()));
+  if (int frc = plane_fft_forward(c)) return frc;
   launch_slab_thomas_local(c);
   LAUNCHCHK(c);
   return EKPNP_OK;
@@ -1178,7 +1182,7 @@ extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
   launch_slab_reduce_correct(c);
-  FFTCHK(c, hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out()));
+  if (int frc = plane_fft_inverse(c)) return frc;
   LAUNCHCHK(c);
   return EKPNP_OK;
 }

@@ -139,6 +139,9 @@ void launch_halo_unpack(Ctx&);
 // poisson.hip
 int build_cprime(Ctx&);  // EKPNP_OK or a status with Ctx::err set
 void launch_poisson_rhs(Ctx&);
+int plane_fft_setup(Ctx&);      // decides Ctx::own_fft for this lattice and device, makes the twiddle table
+int plane_fft_forward(Ctx&);    // fft_in() -> fft_spec(): the own kernels or the rocFFT plan; EKPNP_OK or a status with Ctx::err set
+int plane_fft_inverse(Ctx&);    // fft_spec() -> fft_out()
 void launch_tridiag(Ctx&);
 bool tridiag_prepare_device();  // per-device function attributes of the partition z solves (current device)
 void launch_phi_efield(Ctx&);
@@ -221,6 +224,8 @@ struct Ctx {
   hipGraphExec_t graph2 = nullptr;
   int graph_cur = -1;              // value of `cur` the graph was captured at
   bool graph_failed = false;       // capture is not possible here: stay eager
+  bool own_fft = false;            // the 2-D transforms are the library's own kernels (fft_plane.h), no rocFFT plans
+  double2* fft_tw = nullptr;       // their twiddle table exp(-2 pi i k / 1024)
   hipfftHandle plan_fwd = 0, plan_inv = 0;
   bool tri_lds_ok = false;  // this context's device grants the partition z solves their dynamic LDS (tridiag_prepare_device)
   int tri_partition = 1;  // z solve of a single context: 0 serial sweeps, 1 partition solve on large lattices, 2 wherever it applies

@@ -16,8 +16,58 @@
 #include <cstdlib>
 
 #include "ekpnp_internal.h"
+#include "fft_plane.h"
 
 namespace ekpnp {
+
+// ---- the 2-D transforms of the interior planes ---------------------------------------------------------------------
+// rocFFT plans (hipFFT API) everywhere except on planes of 1024 x 1024 (cfg5), where rocFFT has no strided-column kernel
+// and transposes instead (4 + 4 kernels, 3.2 ms per solve on a 1024 x 1024 x 128 slab); there the library's own row and
+// column passes run (fft_plane.h: 0.84 + 0.81 ms).  EKPNP_OWN_FFT=0 at creation keeps rocFFT (the A/B partner).
+int plane_fft_setup(Ctx& c) {
+  c.own_fft = false;
+  const char* e = std::getenv("EKPNP_OWN_FFT");
+  if (e && std::atoi(e) == 0) return EKPNP_OK;
+  if (!fft_x_supported(c.p.nx) || c.p.ny != 1024 || !fft_y_supported(c.p.ny, c.nxh)) return EKPNP_OK;
+  if (!fft_x_prepare() || !fft_y_prepare(c.p.ny)) return EKPNP_OK;  // this device does not grant the LDS: rocFFT
+  std::vector<double2> h(1024);
+  fft_y_twiddles(1024, h.data());
+  hipError_t he = hipMalloc((void**)&c.fft_tw, h.size() * sizeof(double2));
+  if (he == hipSuccess) he = hipMemcpy(c.fft_tw, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice);
+  if (he != hipSuccess) {
+    c.err = std::string("twiddle table of the plane transforms: ") + hipGetErrorString(he);
+    return he == hipErrorOutOfMemory ? EKPNP_ERR_NOMEM : EKPNP_ERR_HIP;
+  }
+  c.bytes += h.size() * sizeof(double2);
+  c.own_fft = true;
+  return EKPNP_OK;
+}
+
+int plane_fft_forward(Ctx& c) {
+  if (c.own_fft) {
+    fft_x_forward(c.fft_in(), reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
+    note_launch(c, "k_fft_x1024_r2c");
+    fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.p.ny, c.nxh, c.fft_nz, -1, c.stream);
+    note_launch(c, "k_fft_y1024<-1>");
+    return EKPNP_OK;
+  }
+  const hipfftResult r = hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec());
+  if (r != HIPFFT_SUCCESS) { c.err = "hipfftExecD2Z: hipfft error " + std::to_string((int)r); return EKPNP_ERR_FFT; }
+  return EKPNP_OK;
+}
+
+int plane_fft_inverse(Ctx& c) {
+  if (c.own_fft) {
+    fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.p.ny, c.nxh, c.fft_nz, +1, c.stream);
+    note_launch(c, "k_fft_y1024<1>");
+    fft_x_inverse(reinterpret_cast<const double2*>(c.fft_spec()), c.fft_out(), c.fft_tw, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
+    note_launch(c, "k_fft_x1024_c2r");
+    return EKPNP_OK;
+  }
+  const hipfftResult r = hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out());
+  if (r != HIPFFT_SUCCESS) { c.err = "hipfftExecZ2D: hipfft error " + std::to_string((int)r); return EKPNP_ERR_FFT; }
+  return EKPNP_OK;
+}
 
 // rhs of the interior planes, poisson.cu:114-135: g = -F (c - cn)/eps, wall potentials folded
 // into the planes next to the walls; wall planes themselves carry 0.

@@ -857,3 +857,30 @@ print("REPORT", json.dumps(rep))
             outs.append(np.load(out))
         for k in outs[0].files:
             assert np.isfinite(outs[0][k]).all() and np.array_equal(outs[0][k], outs[1][k]), (in_place, k)
+
+
+def test_own_plane_transforms_equal_rocfft(pkg, O, monkeypatch):
+    """Planes of 1024 x 1024 (cfg5) are transformed by the library's own row and column kernels (csrc/fft_plane.h: 2 + 2
+    kernels per solve, rocFFT needs 4 + 4 there); EKPNP_OWN_FFT=0 at creation keeps the rocFFT plans.  The two must give
+    the same Poisson solve to rounding: random concentrations, one context (k_tridiag_pcr64 / serial z solve) and two
+    slabs (the distributed solve), phi and E.  The own path against the ORACLE at this width:
+    tests/test_group_gpu.py::test_interior_rank_at_cfg5_width_vs_oracle."""
+    rng = np.random.default_rng(3)
+    shape = (1024, 1024, 10)
+    p = pkg.default_params(*shape)
+    cc, cn = 0.01 * (1 + 0.5 * rng.random(shape[::-1])), 0.01 * (1 + 0.5 * rng.random(shape[::-1]))
+    res = {}
+    for own in ("1", "0"):
+        monkeypatch.setenv("EKPNP_OWN_FFT", own)
+        for nslabs in (1, 2):
+            with (pkg.Solver(p) if nslabs == 1 else pkg.Group(p, 2, devices=[0, 0])) as s:
+                s.set_field("c", cc)
+                s.set_field("cn", cn)
+                s.fast_Poisson()
+                res[own, nslabs] = {k: s.get_field(k) for k in ("phi", "Ex", "Ey", "Ez")}
+    for nslabs in (1, 2):
+        a, b = res["1", nslabs], res["0", nslabs]
+        assert all(np.isfinite(v).all() for v in a.values())
+        err = O.rel_l2(a, b, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
+        assert err["phi"] < 1e-13 and err["E"] < 1e-11, (nslabs, err)
+        assert not np.array_equal(a["phi"], b["phi"])  # two different transform paths did run

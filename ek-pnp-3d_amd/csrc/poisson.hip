@@ -243,35 +243,48 @@ __device__ __forceinline__ double recip(double x) {
 // (rows = the slab's own unknown rows; x just below the first and just above the last row are the interface values
 // `bound` = (g_lo.re, g_lo.im, g_hi.re, g_hi.im)[modes] that k_slab_interface made from the gathered edge values:
 // they move to the right-hand side of the first and the last row).
-template <int R, bool SLAB>
+// LANES (round 3): lanes of a wavefront that share one mode.  64 = one wavefront per mode (8 modes per workgroup, columns
+// of up to 64 R rows).  Short columns - cfg5's and cfg4@8's 128-plane slabs - would leave R = 2 rows per lane, and the
+// cyclic reduction (6 levels of lane exchanges per 2 KB of column) becomes the whole cost: 0.77 ms for the bytes the
+// R = 8 kernel moves in 0.56.  With LANES = 16 (32) a wavefront holds 4 (2) modes of 16 R (32 R) rows, the reduction has
+// 4 (5) levels and serves all of them at once, and a workgroup covers 32 (16) adjacent modes: 512 (256) contiguous
+// bytes per row.
+template <int R, int LANES, bool SLAB>
 __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __restrict__ rows, const int n, const double* __restrict__ bound) {
-  extern __shared__ double2 tp_lds[];  // [64 R slots][8 columns]
+  constexpr int MPW = 64 / LANES;        // modes per wavefront
+  constexpr int MC = 8 * MPW;            // modes (LDS columns) per workgroup of 8 wavefronts
+  static_assert(LANES * R <= 512 && 64 % LANES == 0, "a column has LANES x R row slots");
+  constexpr int TR = 512 / MC;           // rows loaded per pass of the workgroup
+  constexpr int FM = (MC < 16 ? MC : 16) - 1;  // the column index is XOR-ed with the owning lane (mod 16 columns = 256 bytes of banks)
+  extern __shared__ double2 tp_lds[];    // [LANES R slots][MC columns] = R x 8 KB
   const long long ms = (long long)a.ny * a.nxh;
-  const long long m0 = (long long)blockIdx.x * 8;
+  const long long m0 = (long long)blockIdx.x * MC;
   {
-    const int c = threadIdx.x & 7, t = threadIdx.x >> 3;
+    const int c = threadIdx.x % MC, t = threadIdx.x / MC;
     const double2* src = rows + m0 + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int s = t + 64 * r;
+      const int s = t + TR * r;
       double2 v = make_double2(0.0, 0.0);
       if (s < n) v = src[(long long)s * ms];
-      tp_lds[s * 8 + (c ^ ((s / R) & 7))] = v;
+      tp_lds[s * MC + (c ^ ((s / R) & FM))] = v;
     }
   }
   __syncthreads();
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const double b = mode_diag((int)(m0 + w), a.ny, a.nxh, a.Lx, a.Ly, a.dz);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l = lane % LANES;                 // lane within its mode: owns slots R l .. R l + R - 1
+  const int col = w * MPW + lane / LANES;     // the mode among the workgroup's MC
+  const double b = mode_diag((int)(m0 + col), a.ny, a.nxh, a.Lx, a.Ly, a.dz);
   const double dz2 = a.dz * a.dz;
-  double2* mine = tp_lds + (R * l) * 8 + (w ^ (l & 7));
+  double2* mine = tp_lds + (R * l) * MC + (col ^ (l & FM));
   double2 g[R];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
-    const double2 r = mine[k * 8];
+    const double2 r = mine[k * MC];
     g[k] = make_double2(dz2 * r.x, dz2 * r.y);
   }
   if (SLAB) {
-    const double* bw = bound + m0 + w;
+    const double* bw = bound + m0 + col;
     const double glr = bw[0], gli = bw[ms], ghr = bw[2 * ms], ghi = bw[3 * ms];
     if (l == 0) g[0] = make_double2(g[0].x - glr, g[0].y - gli);
 #pragma unroll
@@ -307,28 +320,28 @@ __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __res
       wv[k] = -cp[k] * wv[k + 1];
     }
   }
-  // the interface row (slot R l + R - 1) in terms of y[l-1], y[l], y[l+1]
+  // the interface row (slot R l + R - 1) in terms of y[l-1], y[l], y[l+1]; lane exchanges stay inside the LANES lanes of a mode
   double lo, up, bd, rr, ri;
   {
     const int s = R * l + R - 1;
     const bool real = s < n;
     const double A7 = real ? 1.0 : 0.0, B7 = real ? b : 1.0, C7 = (real && s < n - 1) ? 1.0 : 0.0;
-    const double g0x = __shfl_down(g[0].x, 1, 64), g0y = __shfl_down(g[0].y, 1, 64);
-    const double v0n = __shfl_down(v[0], 1, 64), w0n = __shfl_down(wv[0], 1, 64);
+    const double g0x = __shfl_down(g[0].x, 1, LANES), g0y = __shfl_down(g[0].y, 1, LANES);
+    const double v0n = __shfl_down(v[0], 1, LANES), w0n = __shfl_down(wv[0], 1, LANES);
     lo = -A7 * v[R - 2];
     bd = B7 - A7 * wv[R - 2] - C7 * v0n;
     up = -C7 * w0n;
     rr = g[R - 1].x - A7 * g[R - 2].x - C7 * g0x;
     ri = g[R - 1].y - A7 * g[R - 2].y - C7 * g0y;
-    if (l == 63) up = 0.0;
+    if (l == LANES - 1) up = 0.0;
     if (l == 0) lo = 0.0;
   }
 #pragma unroll
-  for (int st = 1; st < 64; st <<= 1) {
-    double lo_l = __shfl_up(lo, st, 64), up_l = __shfl_up(up, st, 64), bd_l = __shfl_up(bd, st, 64);
-    double rr_l = __shfl_up(rr, st, 64), ri_l = __shfl_up(ri, st, 64);
-    double lo_u = __shfl_down(lo, st, 64), up_u = __shfl_down(up, st, 64), bd_u = __shfl_down(bd, st, 64);
-    double rr_u = __shfl_down(rr, st, 64), ri_u = __shfl_down(ri, st, 64);
+  for (int st = 1; st < LANES; st <<= 1) {
+    double lo_l = __shfl_up(lo, st, LANES), up_l = __shfl_up(up, st, LANES), bd_l = __shfl_up(bd, st, LANES);
+    double rr_l = __shfl_up(rr, st, LANES), ri_l = __shfl_up(ri, st, LANES);
+    double lo_u = __shfl_down(lo, st, LANES), up_u = __shfl_down(up, st, LANES), bd_u = __shfl_down(bd, st, LANES);
+    double rr_u = __shfl_down(rr, st, LANES), ri_u = __shfl_down(ri, st, LANES);
     // a lane without a partner at this distance has lo (up) == 0 - an invariant of the reduction, true of the start
     // values - so whatever finite values its shuffle returned (its own) are multiplied by zero: no selects needed
     const double al = -lo * recip(bd_l), ga = -up * recip(bd_u);
@@ -340,34 +353,34 @@ __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __res
   }
   const double ibd = recip(bd);
   const double yx = rr * ibd, yy = ri * ibd;
-  double ylx = __shfl_up(yx, 1, 64), yly = __shfl_up(yy, 1, 64);
+  double ylx = __shfl_up(yx, 1, LANES), yly = __shfl_up(yy, 1, LANES);
   if (l == 0) { ylx = 0.0; yly = 0.0; }
   // 1/(NX NY) of the unnormalised transforms folded in, as in k_tridiag
 #pragma unroll
   for (int k = 0; k < R - 1; ++k)
-    mine[k * 8] = make_double2((g[k].x - ylx * v[k] - yx * wv[k]) * a.inv_nxny, (g[k].y - yly * v[k] - yy * wv[k]) * a.inv_nxny);
-  mine[(R - 1) * 8] = make_double2(yx * a.inv_nxny, yy * a.inv_nxny);
+    mine[k * MC] = make_double2((g[k].x - ylx * v[k] - yx * wv[k]) * a.inv_nxny, (g[k].y - yly * v[k] - yy * wv[k]) * a.inv_nxny);
+  mine[(R - 1) * MC] = make_double2(yx * a.inv_nxny, yy * a.inv_nxny);
   __syncthreads();
   {
-    const int c = threadIdx.x & 7, t = threadIdx.x >> 3;
+    const int c = threadIdx.x % MC, t = threadIdx.x / MC;
     double2* dst = rows + m0 + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int s = t + 64 * r;
-      if (s < n) TRI_STORE(dst + (long long)s * ms, tp_lds[s * 8 + (c ^ ((s / R) & 7))]);
+      const int s = t + TR * r;
+      if (s < n) TRI_STORE(dst + (long long)s * ms, tp_lds[s * MC + (c ^ ((s / R) & FM))]);
     }
   }
 }
 
-template <int R>
+template <int R, int LANES = 64>
 __global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
-  tridiag_part_body<R, false>(a, a.spec + (long long)a.ny * a.nxh, a.nz - 2, nullptr);
+  tridiag_part_body<R, LANES, false>(a, a.spec + (long long)a.ny * a.nxh, a.nz - 2, nullptr);
 }
 
 // z slab: the same solve on the slab's m unknown rows (first one on local plane row_a), spectrum read once
-template <int R>
+template <int R, int LANES = 64>
 __global__ void __launch_bounds__(512) k_slab_part(PArgs a, int row_a, int m, const double* __restrict__ bound) {
-  tridiag_part_body<R, true>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound);
+  tridiag_part_body<R, LANES, true>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound);
 }
 
 // Short channels (NZ - 2 <= 64 unknown rows, e.g. the reference's own 51 planes): the serial
@@ -958,6 +971,11 @@ int build_cprime(Ctx& c) {
 // Slabs of up to 512 unknown rows take the read-once pair (k_slab_edges + k_slab_part: the spectrum is read once for
 // the solve, plus the few rows at either end of the block for the edge values); taller slabs and
 // ekpnp_tune(ctx, "tri_partition", 0) (the A/B partner) keep the serial pair k_slab_thomas_local + k_slab_reduce_correct.
+// EKPNP_TRI_WIDE_MODES=0: one wavefront per mode also on short columns (the A/B partner of LANES = 16 / 32)
+static inline bool wide_modes() {
+  static const bool on = !(std::getenv("EKPNP_TRI_WIDE_MODES") && std::atoi(std::getenv("EKPNP_TRI_WIDE_MODES")) == 0);
+  return on;
+}
 static inline bool slab_read_once(const Ctx& c) { return c.tri_partition > 0 && c.tri_lds_ok && c.nxh % 8 == 0 && c.slab_m >= 1 && c.slab_m <= 512; }
 
 void launch_slab_thomas_local(Ctx& c) {
@@ -980,14 +998,21 @@ void launch_slab_reduce_correct(Ctx& c) {
   note_launch(c, "k_slab_interface");
   if (slab_read_once(c)) {
     const int m = c.slab_m;
-    if (m <= 128) {
-      hipLaunchKernelGGL(k_slab_part<2>, dim3(nm / 8), dim3(512), 64 * 2 * 8 * sizeof(double2), c.stream, a, c.slab_row_a, m, c.edge_local);
+    // short columns: several modes per wavefront (tridiag_part_body's LANES) where the mode count allows whole workgroups
+    if (m <= 128 && wide_modes() && nm % 32 == 0) {
+      hipLaunchKernelGGL((k_slab_part<8, 16>), dim3(nm / 32), dim3(512), 8 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
+      note_launch(c, "k_slab_part<8,16>");
+    } else if (m <= 128) {
+      hipLaunchKernelGGL((k_slab_part<2, 64>), dim3(nm / 8), dim3(512), 2 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
       note_launch(c, "k_slab_part<2>");
+    } else if (m <= 256 && wide_modes() && nm % 16 == 0) {
+      hipLaunchKernelGGL((k_slab_part<8, 32>), dim3(nm / 16), dim3(512), 8 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
+      note_launch(c, "k_slab_part<8,32>");
     } else if (m <= 256) {
-      hipLaunchKernelGGL(k_slab_part<4>, dim3(nm / 8), dim3(512), 64 * 4 * 8 * sizeof(double2), c.stream, a, c.slab_row_a, m, c.edge_local);
+      hipLaunchKernelGGL((k_slab_part<4, 64>), dim3(nm / 8), dim3(512), 4 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
       note_launch(c, "k_slab_part<4>");
     } else {
-      hipLaunchKernelGGL(k_slab_part<8>, dim3(nm / 8), dim3(512), 64 * 8 * 8 * sizeof(double2), c.stream, a, c.slab_row_a, m, c.edge_local);
+      hipLaunchKernelGGL((k_slab_part<8, 64>), dim3(nm / 8), dim3(512), 8 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
       note_launch(c, "k_slab_part<8>");
     }
     return;
@@ -1011,12 +1036,20 @@ void launch_poisson_rhs(Ctx& c) {
 // the dynamic-LDS limit of the partition solves is a per-DEVICE function attribute: set when a context is made, on
 // the device it is made on (ekpnp_group_* drives contexts on several devices from one process)
 bool tridiag_prepare_device() {
-  const hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_part<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 8 * 8 * (int)sizeof(double2));
-  const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_part<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 4 * 8 * (int)sizeof(double2));
-  const hipError_t s8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_part<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 8 * 8 * (int)sizeof(double2));
-  const hipError_t s4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_part<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 4 * 8 * (int)sizeof(double2));
-  const hipError_t s2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_part<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 2 * 8 * (int)sizeof(double2));
-  if (e8 != hipSuccess || e4 != hipSuccess || s8 != hipSuccess || s4 != hipSuccess || s2 != hipSuccess) { (void)hipGetLastError(); return false; }
+  hipError_t e = hipSuccess;
+  auto lds = [&](const void* fn, int bytes) {
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  };
+  lds(reinterpret_cast<const void*>(&k_tridiag_part<8, 64>), 8 * 8192);
+  lds(reinterpret_cast<const void*>(&k_tridiag_part<4, 64>), 4 * 8192);
+  lds(reinterpret_cast<const void*>(&k_tridiag_part<8, 32>), 8 * 8192);
+  lds(reinterpret_cast<const void*>(&k_tridiag_part<8, 16>), 8 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_part<8, 64>), 8 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_part<4, 64>), 4 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_part<2, 64>), 2 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_part<8, 32>), 8 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_part<8, 16>), 8 * 8192);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
   return true;
 }
 
@@ -1032,11 +1065,17 @@ void launch_tridiag(Ctx& c) {
   if (rows <= 64) {
     hipLaunchKernelGGL(k_tridiag_pcr64, dim3((nm + 3) / 4), dim3(256), 0, c.stream, a);
     note_launch(c, "k_tridiag_pcr64");
+  } else if (part && large && rows <= 128 && wide_modes() && nm % 32 == 0) {
+    hipLaunchKernelGGL((k_tridiag_part<8, 16>), dim3(nm / 32), dim3(512), 8 * 8192, c.stream, a);
+    note_launch(c, "k_tridiag_part<8,16>");
+  } else if (part && large && rows <= 256 && wide_modes() && nm % 16 == 0) {
+    hipLaunchKernelGGL((k_tridiag_part<8, 32>), dim3(nm / 16), dim3(512), 8 * 8192, c.stream, a);
+    note_launch(c, "k_tridiag_part<8,32>");
   } else if (part && large && rows <= 256) {
-    hipLaunchKernelGGL(k_tridiag_part<4>, dim3(nm / 8), dim3(512), 64 * 4 * 8 * sizeof(double2), c.stream, a);
+    hipLaunchKernelGGL((k_tridiag_part<4, 64>), dim3(nm / 8), dim3(512), 4 * 8192, c.stream, a);
     note_launch(c, "k_tridiag_part<4>");
   } else if (part && large && rows <= 512) {
-    hipLaunchKernelGGL(k_tridiag_part<8>, dim3(nm / 8), dim3(512), 64 * 8 * 8 * sizeof(double2), c.stream, a);
+    hipLaunchKernelGGL((k_tridiag_part<8, 64>), dim3(nm / 8), dim3(512), 8 * 8192, c.stream, a);
     note_launch(c, "k_tridiag_part<8>");
   } else {
     hipLaunchKernelGGL(k_tridiag, dim3((nm + EKPNP_TRI_THREADS - 1) / EKPNP_TRI_THREADS), dim3(EKPNP_TRI_THREADS), 0, c.stream, a);

@@ -760,7 +760,8 @@ def test_partition_z_solve_random_channel_heights(pkg, O):
 
 
 @pytest.mark.parametrize("shape,kernel", [((16, 8, 514), "k_tridiag_part<8>, all 64 lanes full"), ((24, 6, 300), "k_tridiag_part<8>, identity rows"),
-                                          ((20, 4, 131), "k_tridiag_part<4>")])
+                                          ((20, 4, 131), "k_tridiag_part<8,32>: two modes per wavefront"), ((12, 3, 131), "k_tridiag_part<4> (24 modes: no whole wide workgroup)"),
+                                          ((20, 4, 100), "k_tridiag_part<8,16>: four modes per wavefront"), ((40, 8, 130), "k_tridiag_part<8,16>, all 16 lanes full")])
 def test_partition_z_solve_vs_oracle(pkg, O, shape, kernel):
     """k_tridiag_part<8> - the z solve the cfg3 bench times - and <4> against the ORACLE (its 3-D DFT of the odd
     extension, poisson.cu:105-204), not against the serial HIP sweeps: tune("tri_partition", 2) takes the partition
@@ -795,7 +796,7 @@ def test_partition_z_solve_vs_oracle(pkg, O, shape, kernel):
     finally:
         sol.close()
         orc.close()
-    _assert_all(res, name=f"partition_z_solve_vs_oracle_{shape[2]}")
+    _assert_all(res, name=f"partition_z_solve_vs_oracle_{shape[0]}x{shape[2]}")
 
 
 @pytest.mark.parametrize("dz", [1.0e-11, 1.0e-5])

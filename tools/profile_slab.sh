@@ -14,6 +14,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 T=$(find "$OUT" -name "*kernel_trace.csv" | head -1)
 S=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 python3 "$ROOT/tools/overlap_trace.py" "$T" > "$ROOT/gpurun_out/${TAG}_slab_overlap.json" && cp "$S" "$ROOT/gpurun_out/${TAG}_slab_kernel_stats.csv"
+python3 "$ROOT/tools/step_timeline.py" "$T" > "$ROOT/gpurun_out/${TAG}_slab_last_step_timeline.json" 2>/dev/null || true
 grep '"metric"' "$OUT/trace.log" | tail -1 > "$ROOT/gpurun_out/${TAG}_slab_bench_line_under_profiler.json"
 rm -rf "$OUT/trace"   # the per-dispatch trace is large; the three summaries above are what is kept
 head -c 1500 "$ROOT/gpurun_out/${TAG}_slab_overlap.json"

@@ -381,9 +381,15 @@ __global__ void __launch_bounds__(64 * FX_ROWS) k_fft_x1024_c2r(const double2* _
   double2 v[8];
   fx_fft512_from_lds<1>(img, w, t, v);
   if (!live) return;
-  double2* dst = reinterpret_cast<double2*>(out + row * 1024);
+  // the phi array may be caller-bound (ekpnp_bind_field) and then only 8-byte aligned: a 16-byte store through a type
+  // that promises no more than that (global_store_dwordx4 itself needs dword alignment only)
+  typedef double fx_pair8 __attribute__((ext_vector_type(2), aligned(8)));
+  fx_pair8* dst = reinterpret_cast<fx_pair8*>(out + row * 1024);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dst[t + 64 * fy_rev3(i)] = v[i];
+  for (int i = 0; i < 8; ++i) {
+    const fx_pair8 pv = {v[i].x, v[i].y};
+    dst[t + 64 * fy_rev3(i)] = pv;
+  }
 }
 
 inline bool fft_x_supported(int nx) { return nx == 1024; }

@@ -879,6 +879,21 @@ def test_own_plane_transforms_equal_rocfft(pkg, O, monkeypatch):
                 s.set_field("cn", cn)
                 s.fast_Poisson()
                 res[own, nslabs] = {k: s.get_field(k) for k in ("phi", "Ex", "Ey", "Ez")}
+    # the own inverse row pass stores 16 bytes at a time into the phi array: a caller-bound phi that is only 8-byte aligned
+    # (ekpnp_bind_field) must get the same bits
+    import torch
+
+    monkeypatch.setenv("EKPNP_OWN_FFT", "1")
+    with pkg.Solver(p) as s:
+        n = int(np.prod(s.shape))
+        pool = torch.zeros(n + 3, dtype=torch.float64, device="cuda")
+        view = pool[1 : 1 + n]
+        assert view.data_ptr() % 16 == 8
+        s.bind_field("phi", view.data_ptr())
+        s.set_field("c", cc)
+        s.set_field("cn", cn)
+        s.fast_Poisson()
+        assert np.array_equal(s.get_field("phi"), res["1", 1]["phi"]) and np.array_equal(s.get_field("Ez"), res["1", 1]["Ez"])
     for nslabs in (1, 2):
         a, b = res["1", nslabs], res["0", nslabs]
         assert all(np.isfinite(v).all() for v in a.values())

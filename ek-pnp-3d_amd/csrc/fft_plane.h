@@ -19,11 +19,16 @@
 // Unnormalised in both directions, like cuFFT / rocFFT.  The spectrum row pitch nxh is a multiple of 8 (capi.hip); the
 // padding columns beyond NX/2 are transformed along (never read by anyone).
 //
+// Planes of 512 rows / 512 columns are supported too (256-point row transform, 512-point column transform) but NOT the
+// default there: rocFFT's 2 + 2 kernels on 512 x 512 planes run 0.90 + 0.86 ms, these 0.88 + 0.84 ms
+// (profiles/r03_own_plane_fft_probe.log) - nothing to gain, so cfg3 / cfg4 stay on rocFFT unless EKPNP_OWN_FFT=1.
+//
 // Header-only so that tools/fft_y_probe.hip times exactly the code the library runs.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 namespace ekpnp {
 
@@ -137,6 +142,55 @@ __device__ __forceinline__ int fy_row(int r) { return r ^ ((r >> 4) & 3); }
 __device__ __forceinline__ int fy_row(int r) { return r; }
 #endif
 
+// ---- 512 rows, 4 columns per workgroup (round 3): radix 8 x 8 x 8 like k_fft_y512, but 64 bytes per row and workgroup,
+// 40 KB of LDS (4 workgroups per CU instead of 2), the two halves of a line paired on one XCD like k_fft_y1024
+__device__ __forceinline__ int fy_row8(int r) { return r ^ ((r >> 3) & 3); }  // stage 0 writes rows 8 t + k for neighbouring t
+template <int SIGN>
+__global__ void __launch_bounds__(256) k_fft_y512c4(double2* __restrict__ spec, const double2* __restrict__ tw, int nxh, long long plane_stride, int npairs) {
+  constexpr int N = 512, COLS = 4;
+  extern __shared__ double2 fy_lds[];
+  double2* buf = fy_lds;            // [512 rows][4 columns]
+  double2* w = fy_lds + N * COLS;   // exp(-2 pi i k / 512)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot >> 1) * 8 + xcd, half = slot & 1;
+  if (pair >= npairs) return;  // uniform over the workgroup
+  const int groups = nxh >> 3;
+  const int plane = pair / groups, group = pair - plane * groups;
+  const int c = threadIdx.x & 3, t = threadIdx.x >> 2;  // column, butterfly 0..63
+  double2* base = spec + (long long)plane * plane_stride + (long long)group * 8 + half * COLS + c;
+  double2 v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = base[(long long)(t + 64 * r) * nxh];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) w[threadIdx.x + 256 * i] = tw[threadIdx.x + 256 * i];
+  fy_dft8<SIGN>(v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) buf[fy_row8(8 * t + fy_rev3(i)) * COLS + c] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = buf[fy_row8(t + 64 * r) * COLS + c];
+  {
+    const int k = t & 7;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = fy_mul_tw<SIGN>(v[r], w[k * r * 8]);
+  }
+  fy_dft8<SIGN>(v);
+  __syncthreads();
+  {
+    const int j0 = (t >> 3) * 64 + (t & 7);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[fy_row8(j0 + 8 * fy_rev3(i)) * COLS + c] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = buf[fy_row8(t + 64 * r) * COLS + c];
+#pragma unroll
+  for (int r = 1; r < 8; ++r) v[r] = fy_mul_tw<SIGN>(v[r], w[t * r]);
+  fy_dft8<SIGN>(v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) base[(long long)(t + 64 * fy_rev3(i)) * nxh] = v[i];
+}
+
 // ---- 1024 rows: radix 16 x 8 x 8, 4 columns per workgroup -----------------------------------------------------------
 // Workgroup -> (plane, 8-column group, half): workgroups are dealt round-robin to the 8 XCDs (bid % 8), and the two
 // halves of one 128-byte line group are consecutive slots of ONE XCD, so the second one finds the lines in that L2.
@@ -234,6 +288,8 @@ inline bool fft_y_prepare(int ny) {
   if (ny == 512) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_y512<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fy_lds_bytes(512, 8));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_y512<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fy_lds_bytes(512, 8));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_y512c4<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fy_lds_bytes(512, 4));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_y512c4<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fy_lds_bytes(512, 4));
   } else {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_y1024<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fy_lds_bytes(1024, 4));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_y1024<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fy_lds_bytes(1024, 4));
@@ -247,11 +303,22 @@ inline void fft_y_launch(double2* spec, const double2* tw, int ny, int nxh, int 
   if (nplanes <= 0) return;
   const long long ps = (long long)ny * nxh;
   if (ny == 512) {
-    const dim3 grid(nxh / 8, nplanes);
-    if (sign < 0)
-      hipLaunchKernelGGL(k_fft_y512<-1>, grid, dim3(512), fy_lds_bytes(512, 8), stream, spec, tw, nxh, ps);
-    else
-      hipLaunchKernelGGL(k_fft_y512<1>, grid, dim3(512), fy_lds_bytes(512, 8), stream, spec, tw, nxh, ps);
+    // EKPNP_FFTY512_COLS=8: the 8-column kernel of round 2 (the A/B partner)
+    static const bool cols8 = std::getenv("EKPNP_FFTY512_COLS") != nullptr && std::atoi(std::getenv("EKPNP_FFTY512_COLS")) == 8;
+    if (cols8) {
+      const dim3 grid(nxh / 8, nplanes);
+      if (sign < 0)
+        hipLaunchKernelGGL(k_fft_y512<-1>, grid, dim3(512), fy_lds_bytes(512, 8), stream, spec, tw, nxh, ps);
+      else
+        hipLaunchKernelGGL(k_fft_y512<1>, grid, dim3(512), fy_lds_bytes(512, 8), stream, spec, tw, nxh, ps);
+    } else {
+      const int npairs = nplanes * (nxh / 8);
+      const unsigned blocks = (unsigned)((npairs + 7) / 8) * 8 * 2;
+      if (sign < 0)
+        hipLaunchKernelGGL(k_fft_y512c4<-1>, dim3(blocks), dim3(256), fy_lds_bytes(512, 4), stream, spec, tw, nxh, ps, npairs);
+      else
+        hipLaunchKernelGGL(k_fft_y512c4<1>, dim3(blocks), dim3(256), fy_lds_bytes(512, 4), stream, spec, tw, nxh, ps, npairs);
+    }
   } else {
     const int npairs = nplanes * (nxh / 8);
     const unsigned blocks = (unsigned)((npairs + 7) / 8) * 8 * 2;
@@ -263,150 +330,206 @@ inline void fft_y_launch(double2* spec, const double2* tw, int ny, int nxh, int 
 }
 
 
-// ---- x pass: rows of 1024 real values <-> 513 complex ones (pitch nxh) ---------------------------------------------
-// A real row x[0..1023] is read as 512 complex numbers z[n] = x[2n] + i x[2n+1]; one wavefront per row does the 512-point
-// complex transform (radix 8 x 8 x 8, the row's own padded LDS image: one pad element per 8, so that the stride-8 accesses
-// of the stages fall on different banks) and the even/odd split of the real transform:
-//   forward  Z = FFT512(z), E[k] = (Z[k] + conj Z[512-k]) / 2, O[k] = (Z[k] - conj Z[512-k]) / 2i, w_k = exp(-2 pi i k / 1024):
-//            X[k] = E[k] + w_k O[k],  X[512-k] = conj(E[k] - w_k O[k]),  k = 0..256
-//   inverse  A = X[k], B = conj X[512-k]:  Z[k] = (A + B) + i (A - B) conj(w_k),  Z[512-k] = conj(A + B) + i conj(A - B) w_k,
-//            z = IFFT512(Z) (unnormalised), x[2n] + i x[2n+1] = z[n]
+// ---- x pass: rows of NX real values <-> NX/2 + 1 complex ones (pitch nxh), NX = 1024 or 512 ------------------------
+// A real row x[0..NX-1] is read as N = NX/2 complex numbers z[n] = x[2n] + i x[2n+1]; one wavefront per row does the
+// N-point complex transform (N = 512: radix 8 x 8 x 8, N = 256: radix 4 x 4 x 4 x 4; constant-geometry Stockham through
+// the row's own padded LDS image - one pad element per 8, so that the strided accesses of the stages fall on different
+// banks) and the even/odd split of the real transform, w_k = exp(-2 pi i k / NX):
+//   forward  Z = FFT_N(z), E[k] = (Z[k] + conj Z[N-k]) / 2, O[k] = (Z[k] - conj Z[N-k]) / 2i:
+//            X[k] = E[k] + w_k O[k],  X[N-k] = conj(E[k] - w_k O[k]),  k = 0..N/2
+//   inverse  A = X[k], B = conj X[N-k]:  Z[k] = (A + B) + i (A - B) conj(w_k),  Z[N-k] = conj(A + B) + i conj(A - B) w_k,
+//            z = IFFT_N(Z) (unnormalised), x[2n] + i x[2n+1] = z[n]
 // Lanes hold consecutive elements, so every global access of a wave is one contiguous kilobyte.  FX_ROWS rows per
-// workgroup share the 16 KB twiddle table exp(-2 pi i k / 1024) in LDS.
-constexpr int FX_ROWS = 4, FX_PITCH = 512 + 64;  // padded row image: index i -> i + i / 8
-__device__ __forceinline__ int fx_pad(int i) { return i + (i >> 3); }
-constexpr size_t fx_lds_bytes() { return (size_t)(FX_ROWS * FX_PITCH + 1024) * sizeof(double2); }
+// workgroup share the twiddle table exp(-2 pi i k / NX) in LDS.
+constexpr int FX_ROWS = 4;
+__device__ __forceinline__ int fx_pad(int i) { return i + (i >> 3); }  // padded row image: index i -> i + i / 8
+constexpr size_t fx_lds_bytes(int nx) { return (size_t)(FX_ROWS * (nx / 2 + nx / 16) + nx) * sizeof(double2); }
 
-// 512-point complex transform of the wave's row image `img` (natural order in LDS in, result in registers:
-// v[i] = Z[t + 64 fy_rev3(i)]); w1024 = exp(-2 pi i k / 1024), so exp(-2 pi i k / 512) = w1024[2 k]
+// 4-point DFT, natural order in and out
 template <int SIGN>
-__device__ __forceinline__ void fx_fft512_from_lds(double2* img, const double2* w1024, int t, double2 (&v)[8]) {
-#pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = img[fx_pad(t + 64 * r)];
-  __syncthreads();
-  fy_dft8<SIGN>(v);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) img[fx_pad(8 * t + fy_rev3(i))] = v[i];
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = img[fx_pad(t + 64 * r)];
-  {
-    const int k = t & 7;
-#pragma unroll
-    for (int r = 1; r < 8; ++r) v[r] = fy_mul_tw<SIGN>(v[r], w1024[k * r * 16]);
-  }
-  fy_dft8<SIGN>(v);
-  __syncthreads();
-  {
-    const int j0 = (t >> 3) * 64 + (t & 7);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) img[fx_pad(j0 + 8 * fy_rev3(i))] = v[i];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = img[fx_pad(t + 64 * r)];
-#pragma unroll
-  for (int r = 1; r < 8; ++r) v[r] = fy_mul_tw<SIGN>(v[r], w1024[t * r * 2]);
-  fy_dft8<SIGN>(v);
+__device__ __forceinline__ void fy_dft4(double2 (&v)[4]) {
+  fy_bfly(v[0], v[2]);
+  fy_bfly(v[1], v[3]);
+  v[3] = fy_mul_i<SIGN>(v[3]);
+  const double2 x0 = make_double2(v[0].x + v[1].x, v[0].y + v[1].y), x2 = make_double2(v[0].x - v[1].x, v[0].y - v[1].y);
+  const double2 x1 = make_double2(v[2].x + v[3].x, v[2].y + v[3].y), x3 = make_double2(v[2].x - v[3].x, v[2].y - v[3].y);
+  v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3;
 }
 
-// forward: real rows [nrows][1024] -> half spectrum rows [nrows][nxh] (513 of them written)
-__global__ void __launch_bounds__(64 * FX_ROWS) k_fft_x1024_r2c(const double* __restrict__ in, double2* __restrict__ out, const double2* __restrict__ tw, int nxh, long long nrows) {
+// N-point complex transform of the wave's row image `img` (natural order in LDS in; result in registers: the value of
+// frequency t + 64 f sits in v[slot(f)], slot = fy_rev3 for N = 512, identity for N = 256); wnx = exp(-2 pi i k / NX), NX = 2 N
+template <int SIGN, int N>
+__device__ __forceinline__ void fx_fft_from_lds(double2* img, const double2* wnx, int t, double2 (&v)[N / 64]) {
+  if constexpr (N == 512) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = img[fx_pad(t + 64 * r)];
+    __syncthreads();
+    fy_dft8<SIGN>(v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) img[fx_pad(8 * t + fy_rev3(i))] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = img[fx_pad(t + 64 * r)];
+    {
+      const int k = t & 7;
+#pragma unroll
+      for (int r = 1; r < 8; ++r) v[r] = fy_mul_tw<SIGN>(v[r], wnx[k * r * 16]);
+    }
+    fy_dft8<SIGN>(v);
+    __syncthreads();
+    {
+      const int j0 = (t >> 3) * 64 + (t & 7);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) img[fx_pad(j0 + 8 * fy_rev3(i))] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = img[fx_pad(t + 64 * r)];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = fy_mul_tw<SIGN>(v[r], wnx[t * r * 2]);
+    fy_dft8<SIGN>(v);
+  } else {
+    // N = 256 = 4^4: every stage reads rows t + 64 r, multiplies by exp(-+2 pi i (t mod L) r / (4 L)) and writes the
+    // 4-point DFT to rows (t / L) 4 L + (t mod L) + L k; L = 1, 4, 16, 64 (the last stage stays in registers)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = img[fx_pad(t + 64 * r)];
+    __syncthreads();
+    fy_dft4<SIGN>(v);
+#pragma unroll
+    for (int L = 1; L <= 16; L *= 4) {
+      const int base = (t / L) * 4 * L + (t % L);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) img[fx_pad(base + L * k)] = v[k];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = img[fx_pad(t + 64 * r)];
+      __syncthreads();
+      const int Ln = 4 * L, j = t % Ln;  // next stage: sub-length Ln, twiddle exp(-+2 pi i j r / (4 Ln)) = wnx[j r 512 / (4 Ln)]
+#pragma unroll
+      for (int r = 1; r < 4; ++r) v[r] = fy_mul_tw<SIGN>(v[r], wnx[j * r * (128 / Ln)]);
+      fy_dft4<SIGN>(v);
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ constexpr int fx_slot(int f) { return N == 512 ? fy_rev3(f) : f; }
+
+// forward: real rows [nrows][NX] -> half spectrum rows [nrows][nxh] (NX/2 + 1 of them written)
+template <int NX>
+__global__ void __launch_bounds__(64 * FX_ROWS) k_fft_x_r2c(const double* __restrict__ in, double2* __restrict__ out, const double2* __restrict__ tw, int nxh, long long nrows) {
+  constexpr int N = NX / 2, VPT = N / 64, PITCH = N + N / 8;
   extern __shared__ double2 fx_lds[];
-  double2* w = fx_lds + FX_ROWS * FX_PITCH;
+  double2* w = fx_lds + FX_ROWS * PITCH;
   const int t = threadIdx.x & 63, rw = threadIdx.x >> 6;
-  double2* img = fx_lds + rw * FX_PITCH;
+  double2* img = fx_lds + rw * PITCH;
   const long long row = (long long)blockIdx.x * FX_ROWS + rw;
   const bool live = row < nrows;  // wave-uniform; dead waves still take part in the barriers
-  const double2* src = reinterpret_cast<const double2*>(in + (live ? row : 0) * 1024);
+  const double2* src = reinterpret_cast<const double2*>(in + (live ? row : 0) * NX);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[threadIdx.x + 256 * i] = tw[threadIdx.x + 256 * i];
+  for (int i = 0; i < NX / 256; ++i) w[threadIdx.x + 256 * i] = tw[threadIdx.x + 256 * i];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) img[fx_pad(t + 64 * r)] = src[t + 64 * r];
+  for (int r = 0; r < VPT; ++r) img[fx_pad(t + 64 * r)] = src[t + 64 * r];
   __syncthreads();
-  double2 v[8];
-  fx_fft512_from_lds<-1>(img, w, t, v);
+  double2 v[VPT];
+  fx_fft_from_lds<-1, N>(img, w, t, v);
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) img[fx_pad(t + 64 * fy_rev3(i))] = v[i];  // Z in natural order
+  for (int f = 0; f < VPT; ++f) img[fx_pad(t + 64 * f)] = v[fx_slot<N>(f)];  // Z in natural order
   __syncthreads();
   if (!live) return;
   double2* dst = out + row * nxh;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = t + 64 * j;  // 0 .. 255
-    const double2 zk = img[fx_pad(k)], zn = img[fx_pad((512 - k) & 511)];
+  for (int j = 0; j < VPT / 2; ++j) {
+    const int k = t + 64 * j;  // 0 .. N/2 - 1
+    const double2 zk = img[fx_pad(k)], zn = img[fx_pad((N - k) & (N - 1))];
     const double2 e = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));   // (Z[k] + conj Z[N-k]) / 2
     const double2 o = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));  // (Z[k] - conj Z[N-k]) / 2i
     const double2 a = fy_mul_tw<-1>(o, w[k]);
     dst[k] = make_double2(e.x + a.x, e.y + a.y);
-    dst[512 - k] = make_double2(e.x - a.x, -(e.y - a.y));
+    dst[N - k] = make_double2(e.x - a.x, -(e.y - a.y));
   }
-  if (t == 0) {  // k = 256: X[256] = conj Z[256]
-    const double2 z = img[fx_pad(256)];
-    dst[256] = make_double2(z.x, -z.y);
+  if (t == 0) {  // k = N/2: X[N/2] = conj Z[N/2]
+    const double2 z = img[fx_pad(N / 2)];
+    dst[N / 2] = make_double2(z.x, -z.y);
   }
 }
 
-// inverse: half spectrum rows [nrows][nxh] -> real rows [nrows][1024], unnormalised
-__global__ void __launch_bounds__(64 * FX_ROWS) k_fft_x1024_c2r(const double2* __restrict__ in, double* __restrict__ out, const double2* __restrict__ tw, int nxh, long long nrows) {
+// inverse: half spectrum rows [nrows][nxh] -> real rows [nrows][NX], unnormalised
+template <int NX>
+__global__ void __launch_bounds__(64 * FX_ROWS) k_fft_x_c2r(const double2* __restrict__ in, double* __restrict__ out, const double2* __restrict__ tw, int nxh, long long nrows) {
+  constexpr int N = NX / 2, VPT = N / 64, PITCH = N + N / 8;
   extern __shared__ double2 fx_lds[];
-  double2* w = fx_lds + FX_ROWS * FX_PITCH;
+  double2* w = fx_lds + FX_ROWS * PITCH;
   const int t = threadIdx.x & 63, rw = threadIdx.x >> 6;
-  double2* img = fx_lds + rw * FX_PITCH;
+  double2* img = fx_lds + rw * PITCH;
   const long long row = (long long)blockIdx.x * FX_ROWS + rw;
   const bool live = row < nrows;
   const double2* src = in + (live ? row : 0) * nxh;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[threadIdx.x + 256 * i] = tw[threadIdx.x + 256 * i];
+  for (int i = 0; i < NX / 256; ++i) w[threadIdx.x + 256 * i] = tw[threadIdx.x + 256 * i];
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = t + 64 * j;  // 0 .. 255
-    const double2 a = src[k], xb = src[512 - k];
-    const double2 b = make_double2(xb.x, -xb.y);                       // conj X[512-k]
+  for (int j = 0; j < VPT / 2; ++j) {
+    const int k = t + 64 * j;  // 0 .. N/2 - 1
+    const double2 a = src[k], xb = src[N - k];
+    const double2 b = make_double2(xb.x, -xb.y);                       // conj X[N-k]
     const double2 s = make_double2(a.x + b.x, a.y + b.y), d = make_double2(a.x - b.x, a.y - b.y);
     const double2 dw = fy_mul_tw<1>(d, w[k]);                          // (A - B) conj(w_k)
     img[fx_pad(k)] = make_double2(s.x - dw.y, s.y + dw.x);             // (A + B) + i (A - B) conj(w_k)
     if (k != 0) {
       const double2 dc = fy_mul_tw<-1>(make_double2(d.x, -d.y), w[k]);  // conj(A - B) w_k
-      img[fx_pad(512 - k)] = make_double2(s.x - dc.y, -s.y + dc.x);    // conj(A + B) + i conj(A - B) w_k
+      img[fx_pad(N - k)] = make_double2(s.x - dc.y, -s.y + dc.x);      // conj(A + B) + i conj(A - B) w_k
     }
   }
-  if (t == 0) {  // k = 256: Z[256] = 2 conj X[256]
-    const double2 a = src[256];
-    img[fx_pad(256)] = make_double2(2.0 * a.x, -2.0 * a.y);
+  if (t == 0) {  // k = N/2: Z[N/2] = 2 conj X[N/2]
+    const double2 a = src[N / 2];
+    img[fx_pad(N / 2)] = make_double2(2.0 * a.x, -2.0 * a.y);
   }
   __syncthreads();
-  double2 v[8];
-  fx_fft512_from_lds<1>(img, w, t, v);
+  double2 v[VPT];
+  fx_fft_from_lds<1, N>(img, w, t, v);
   if (!live) return;
   // the phi array may be caller-bound (ekpnp_bind_field) and then only 8-byte aligned: a 16-byte store through a type
   // that promises no more than that (global_store_dwordx4 itself needs dword alignment only)
   typedef double fx_pair8 __attribute__((ext_vector_type(2), aligned(8)));
-  fx_pair8* dst = reinterpret_cast<fx_pair8*>(out + row * 1024);
+  fx_pair8* dst = reinterpret_cast<fx_pair8*>(out + row * NX);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const fx_pair8 pv = {v[i].x, v[i].y};
-    dst[t + 64 * fy_rev3(i)] = pv;
+  for (int f = 0; f < VPT; ++f) {
+    const double2 z = v[fx_slot<N>(f)];
+    const fx_pair8 pv = {z.x, z.y};
+    dst[t + 64 * f] = pv;
   }
 }
 
-inline bool fft_x_supported(int nx) { return nx == 1024; }
-inline bool fft_x_prepare() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_x1024_r2c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fx_lds_bytes());
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_x1024_c2r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fx_lds_bytes());
+inline bool fft_x_supported(int nx) { return nx == 1024 || nx == 512; }
+inline bool fft_x_prepare(int nx) {
+  hipError_t e;
+  if (nx == 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_x_r2c<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fx_lds_bytes(1024));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_x_c2r<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fx_lds_bytes(1024));
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_x_r2c<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fx_lds_bytes(512));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_x_c2r<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fx_lds_bytes(512));
+  }
   if (e != hipSuccess) { (void)hipGetLastError(); return false; }
   return true;
 }
-// tw = exp(-2 pi i k / 1024) (fft_y_twiddles(1024, .)); nrows = rows of all planes
-inline void fft_x_forward(const double* real, double2* spec, const double2* tw, int nxh, long long nrows, hipStream_t stream) {
+// tw = exp(-2 pi i k / nx), k = 0..nx-1 (fft_y_twiddles(nx, .)); nrows = rows of all planes
+inline void fft_x_forward(const double* real, double2* spec, const double2* tw, int nx, int nxh, long long nrows, hipStream_t stream) {
   if (nrows <= 0) return;
-  hipLaunchKernelGGL(k_fft_x1024_r2c, dim3((unsigned)((nrows + FX_ROWS - 1) / FX_ROWS)), dim3(64 * FX_ROWS), fx_lds_bytes(), stream, real, spec, tw, nxh, nrows);
+  const dim3 grid((unsigned)((nrows + FX_ROWS - 1) / FX_ROWS)), block(64 * FX_ROWS);
+  if (nx == 1024)
+    hipLaunchKernelGGL(k_fft_x_r2c<1024>, grid, block, fx_lds_bytes(1024), stream, real, spec, tw, nxh, nrows);
+  else
+    hipLaunchKernelGGL(k_fft_x_r2c<512>, grid, block, fx_lds_bytes(512), stream, real, spec, tw, nxh, nrows);
 }
-inline void fft_x_inverse(const double2* spec, double* real, const double2* tw, int nxh, long long nrows, hipStream_t stream) {
+inline void fft_x_inverse(const double2* spec, double* real, const double2* tw, int nx, int nxh, long long nrows, hipStream_t stream) {
   if (nrows <= 0) return;
-  hipLaunchKernelGGL(k_fft_x1024_c2r, dim3((unsigned)((nrows + FX_ROWS - 1) / FX_ROWS)), dim3(64 * FX_ROWS), fx_lds_bytes(), stream, spec, real, tw, nxh, nrows);
+  const dim3 grid((unsigned)((nrows + FX_ROWS - 1) / FX_ROWS)), block(64 * FX_ROWS);
+  if (nx == 1024)
+    hipLaunchKernelGGL(k_fft_x_c2r<1024>, grid, block, fx_lds_bytes(1024), stream, spec, real, tw, nxh, nrows);
+  else
+    hipLaunchKernelGGL(k_fft_x_c2r<512>, grid, block, fx_lds_bytes(512), stream, spec, real, tw, nxh, nrows);
 }
 
 }  // namespace ekpnp

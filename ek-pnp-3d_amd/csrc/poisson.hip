@@ -27,11 +27,16 @@ namespace ekpnp {
 int plane_fft_setup(Ctx& c) {
   c.own_fft = false;
   const char* e = std::getenv("EKPNP_OWN_FFT");
-  if (e && std::atoi(e) == 0) return EKPNP_OK;
-  if (!fft_x_supported(c.p.nx) || c.p.ny != 1024 || !fft_y_supported(c.p.ny, c.nxh)) return EKPNP_OK;
-  if (!fft_x_prepare() || !fft_y_prepare(c.p.ny)) return EKPNP_OK;  // this device does not grant the LDS: rocFFT
-  std::vector<double2> h(1024);
-  fft_y_twiddles(1024, h.data());
+  // default: the own passes where rocFFT transposes (1024-long columns); EKPNP_OWN_FFT=1 also on 512-long ones, =0 never
+  const int want = e ? std::atoi(e) : -1;
+  if (want == 0) return EKPNP_OK;
+  if (!fft_x_supported(c.p.nx) || !fft_y_supported(c.p.ny, c.nxh)) return EKPNP_OK;
+  if (want < 0 && c.p.ny != 1024) return EKPNP_OK;
+  if (!fft_x_prepare(c.p.nx) || !fft_y_prepare(c.p.ny)) return EKPNP_OK;  // this device does not grant the LDS: rocFFT
+  // one table serves both passes when the plane is square: exp(-2 pi i k / NX), then exp(-2 pi i k / NY)
+  std::vector<double2> h((size_t)c.p.nx + c.p.ny);
+  fft_y_twiddles(c.p.nx, h.data());
+  fft_y_twiddles(c.p.ny, h.data() + c.p.nx);
   hipError_t he = hipMalloc((void**)&c.fft_tw, h.size() * sizeof(double2));
   if (he == hipSuccess) he = hipMemcpy(c.fft_tw, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice);
   if (he != hipSuccess) {
@@ -45,10 +50,10 @@ int plane_fft_setup(Ctx& c) {
 
 int plane_fft_forward(Ctx& c) {
   if (c.own_fft) {
-    fft_x_forward(c.fft_in(), reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
-    note_launch(c, "k_fft_x1024_r2c");
-    fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.p.ny, c.nxh, c.fft_nz, -1, c.stream);
-    note_launch(c, "k_fft_y1024<-1>");
+    fft_x_forward(c.fft_in(), reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.p.nx, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
+    note_launch(c, "k_fft_x_r2c");
+    fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw + c.p.nx, c.p.ny, c.nxh, c.fft_nz, -1, c.stream);
+    note_launch(c, "k_fft_y<-1>");
     return EKPNP_OK;
   }
   const hipfftResult r = hipfftExecD2Z(c.plan_fwd, c.fft_in(), c.fft_spec());
@@ -58,10 +63,10 @@ int plane_fft_forward(Ctx& c) {
 
 int plane_fft_inverse(Ctx& c) {
   if (c.own_fft) {
-    fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.p.ny, c.nxh, c.fft_nz, +1, c.stream);
-    note_launch(c, "k_fft_y1024<1>");
-    fft_x_inverse(reinterpret_cast<const double2*>(c.fft_spec()), c.fft_out(), c.fft_tw, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
-    note_launch(c, "k_fft_x1024_c2r");
+    fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw + c.p.nx, c.p.ny, c.nxh, c.fft_nz, +1, c.stream);
+    note_launch(c, "k_fft_y<1>");
+    fft_x_inverse(reinterpret_cast<const double2*>(c.fft_spec()), c.fft_out(), c.fft_tw, c.p.nx, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
+    note_launch(c, "k_fft_x_c2r");
     return EKPNP_OK;
   }
   const hipfftResult r = hipfftExecZ2D(c.plan_inv, c.fft_spec(), c.fft_out());

@@ -91,12 +91,12 @@ int main(int argc, char** argv) {
     }
     printf("forward: max |own - rocFFT 2-D| = %.3e of max %.3e\n", worst, big);
   }
-  if (ekpnp::fft_x_supported(nx) && ny == 1024 && ekpnp::fft_x_prepare()) {
+  if (ekpnp::fft_x_supported(nx) && nx == ny && ekpnp::fft_x_prepare(nx)) {
     const long long nrows = (long long)ny * nz;
-    timeit("own rows forward (R2C)", [&] { ekpnp::fft_x_forward(real, specB, tw, nxh, nrows, 0); });
-    timeit("own rows + own columns, forward", [&] { ekpnp::fft_x_forward(real, specB, tw, nxh, nrows, 0); ekpnp::fft_y_launch(specB, tw, ny, nxh, nz, -1, 0); });
+    timeit("own rows forward (R2C)", [&] { ekpnp::fft_x_forward(real, specB, tw, nx, nxh, nrows, 0); });
+    timeit("own rows + own columns, forward", [&] { ekpnp::fft_x_forward(real, specB, tw, nx, nxh, nrows, 0); ekpnp::fft_y_launch(specB, tw, ny, nxh, nz, -1, 0); });
     CK(hipMemset(specB, 0, nspec * sizeof(double2)));
-    ekpnp::fft_x_forward(real, specB, tw, nxh, nrows, 0);
+    ekpnp::fft_x_forward(real, specB, tw, nx, nxh, nrows, 0);
     ekpnp::fft_y_launch(specB, tw, ny, nxh, nz, -1, 0);
     CK(hipDeviceSynchronize());
     std::vector<double2> a((size_t)nxh * ny), b((size_t)nxh * ny);
@@ -112,12 +112,12 @@ int main(int argc, char** argv) {
         }
     }
     printf("forward, own rows + own columns: max |own - rocFFT 2-D| = %.3e of max %.3e\n", worst, big);
-    timeit("own columns + own rows, inverse (C2R)", [&] { ekpnp::fft_y_launch(specB, tw, ny, nxh, nz, +1, 0); ekpnp::fft_x_inverse(specB, back, tw, nxh, nrows, 0); });
-    timeit("own rows inverse alone", [&] { ekpnp::fft_x_inverse(specB, back, tw, nxh, nrows, 0); });
-    ekpnp::fft_x_forward(real, specB, tw, nxh, nrows, 0);
+    timeit("own columns + own rows, inverse (C2R)", [&] { ekpnp::fft_y_launch(specB, tw, ny, nxh, nz, +1, 0); ekpnp::fft_x_inverse(specB, back, tw, nx, nxh, nrows, 0); });
+    timeit("own rows inverse alone", [&] { ekpnp::fft_x_inverse(specB, back, tw, nx, nxh, nrows, 0); });
+    ekpnp::fft_x_forward(real, specB, tw, nx, nxh, nrows, 0);
     ekpnp::fft_y_launch(specB, tw, ny, nxh, nz, -1, 0);
     ekpnp::fft_y_launch(specB, tw, ny, nxh, nz, +1, 0);
-    ekpnp::fft_x_inverse(specB, back, tw, nxh, nrows, 0);
+    ekpnp::fft_x_inverse(specB, back, tw, nx, nxh, nrows, 0);
     CK(hipDeviceSynchronize());
     std::vector<double> r((size_t)nx * ny);
     double rt = 0;
@@ -130,7 +130,7 @@ int main(int argc, char** argv) {
     FK(hipfftExecD2Z(p2f, real, (hipfftDoubleComplex*)specA));
     CK(hipMemcpy(specB, specA, nspec * sizeof(double2), hipMemcpyDeviceToDevice));
     ekpnp::fft_y_launch(specB, tw, ny, nxh, nz, +1, 0);
-    ekpnp::fft_x_inverse(specB, back, tw, nxh, nrows, 0);
+    ekpnp::fft_x_inverse(specB, back, tw, nx, nxh, nrows, 0);
     CK(hipDeviceSynchronize());
     rt = 0;
     for (int z : {0, nz - 1}) {

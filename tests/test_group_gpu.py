@@ -502,3 +502,16 @@ def test_cfg4_planes_decomposed_over_8_slabs_equal_one_context(pkg, O):
             assert err <= (1e-7 if k in ("ux", "uy", "uz") else 1e-9), (k, err)
             del got
         assert abs(g.current() - cur) <= 1e-8 * abs(cur)
+
+
+@pytest.mark.parametrize("shape,nslabs", [((70, 5, 32), 4), ((130, 4, 64), 2)])
+def test_serial_slab_z_solve_still_matches_the_oracle(pkg, O, monkeypatch, shape, nslabs):
+    """Slabs of more than 512 unknown rows (cfg4's 1024 planes on one or two devices in place) and EKPNP_TRI_PARTITION=0 keep
+    the serial pair k_slab_thomas_local + k_slab_reduce_correct of round 2; every other slab test now takes the read-once
+    pair, so this one pins the fallback."""
+    monkeypatch.setenv("EKPNP_TRI_PARTITION", "0")
+    po = O.default_params(*shape)
+    po.pb_iterations = 15
+    ref = _oracle_run(O, po, 7)
+    with pkg.Group(_mirror(pkg, po), nslabs, devices=[0] * nslabs) as g:
+        _drive(O, g, po, ref, 7)

@@ -219,6 +219,18 @@ static int validate(const ekpnp_params* p, int rank, int nranks, std::string& er
 
 static int placement_search(Ctx& c, size_t pitch, int nbuf);
 
+// the population buffers inside their one allocation: A0 A1 A2 A3 B0 B1 B2 B3 (buffer-major; EKPNP_POP_ORDER=1, an
+// experiment of round 3: lattice-major A0 B0 A1 B1 ... - no difference, profiles/r03_direction_sweep.log)
+static void carve_arena(Ctx& c, void* base, size_t pitch) {
+  static const bool lattice_major = std::getenv("EKPNP_POP_ORDER") != nullptr && std::atoi(std::getenv("EKPNP_POP_ORDER")) == 1;
+  const int nb = c.inplace ? 1 : 2, nl = c.p.n_lattices;
+  for (int b = 0; b < nb; ++b)
+    for (int l = 0; l < nl; ++l) {
+      const int k = lattice_major ? l * nb + b : b * nl + l;
+      c.pop[b][l] = (double*)((char*)base + pitch * k);
+    }
+}
+
 static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, ekpnp_ctx** out) {
   if (!out) { g_create_err = "out is NULL"; return EKPNP_ERR_INVALID; }
   *out = nullptr;
@@ -290,9 +302,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
     if (got || hipMalloc(&c.pop_alloc[0][0], pitch * nbuf) == hipSuccess) {
       c.bytes += pitch * nbuf;
       if (std::getenv("EKPNP_DEBUG_ARENA")) std::fprintf(stderr, "ekpnp: population arena %p, %zu buffers of %zu bytes\n", c.pop_alloc[0][0], (size_t)nbuf, pitch);
-      int k = 0;
-      for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
-        for (int l = 0; l < p->n_lattices; ++l, ++k) c.pop[b][l] = (double*)((char*)c.pop_alloc[0][0] + pitch * k);
+      carve_arena(c, c.pop_alloc[0][0], pitch);
     } else {  // no contiguous range of that size (a fragmented device): one allocation per buffer may still fit
       (void)hipGetLastError();
       c.pop_alloc[0][0] = nullptr;
@@ -814,11 +824,7 @@ static int placement_search(Ctx& c, size_t pitch, int nbuf) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
-  auto point_at = [&](void* base) {
-    int k = 0;
-    for (int b = 0; b < (c.inplace ? 1 : 2); ++b)
-      for (int l = 0; l < c.p.n_lattices; ++l, ++k) c.pop[b][l] = (double*)((char*)base + pitch * k);
-  };
+  auto point_at = [&](void* base) { carve_arena(c, base, pitch); };
   const bool streamed0 = c.streamed_state;
   c.streamed_state = false;  // time the kernel the steps run: pull + collide
   int n = 0;

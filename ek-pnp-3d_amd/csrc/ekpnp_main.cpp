@@ -57,6 +57,7 @@ int main(int argc, char* argv[]) {
   std::vector<int> devices;
   std::string out = ".";
   double exf = 0.0, uw = 0.0, chargeinf = -1.0, Ra = -1.0, TH = -1.0;
+  double converged_tol = 0.0;  // > 0: ekpnp_initialization_converged instead of the reference's fixed 501 Picard sweeps
   for (int i = 1; i < argc; ++i) {
     auto val = [&](const char* name) -> const char* {
       if (std::strcmp(argv[i], name) == 0 && i + 1 < argc) return argv[++i];
@@ -88,11 +89,15 @@ int main(int argc, char* argv[]) {
     else if ((v = val("--chargeinf"))) chargeinf = std::atof(v);
     else if ((v = val("--Ra"))) Ra = std::atof(v);
     else if ((v = val("--TH"))) TH = std::atof(v);
+    else if ((v = val("--converged-init"))) converged_tol = std::atof(v);
     else {
       std::fprintf(stderr,
                    "usage: ekpnp_main [--nx N --ny N --nz N] [--steps N] [--nsave N] [--print-current N] [--read-previous 0|1|2]\n"
                    "                  [--binary-state 0|1] [--gpus N [--transport auto|rccl|copy] [--devices d0,d1,...]]\n"
-                   "                  [--lattices 1|3|4] [--exf F --uw U --chargeinf C --Ra R --TH T] [--out DIR]\n"
+                   "                  [--lattices 1|3|4] [--exf F --uw U --chargeinf C --Ra R --TH T] [--out DIR] [--converged-init TOL]\n"
+                   "  --converged-init TOL: Poisson-Boltzmann start-up with a convergence test and a damping that cannot diverge\n"
+                   "  (ekpnp_initialization_converged); the reference's 501 sweeps with PB_omega = 0.05 (LBM.cu:89-106) diverge to NaN on\n"
+                   "  channels taller than about 180 planes at the default spacing.\n"
                    "  --read-previous 1: restart from data_end.dat (%%10.6f text, the reference's); 2: from data_end.bin (--binary-state 1,\n"
                    "  the 11 fields as raw FP64).  Both restarts are the reference's (main.cu:161-175): the populations are rebuilt as the\n"
                    "  EQUILIBRIUM of the fields, so a restarted run is not the bitwise continuation of the interrupted one.\n");
@@ -149,7 +154,14 @@ int main(int argc, char* argv[]) {
     CK(RUN(read_state, f_bin.c_str(), &t));
   } else {  // main.cu:165-171
     std::printf("Initializing...\n");
-    CK(RUN(initialization));
+    if (converged_tol > 0.0) {
+      int sweeps = 0;
+      double res = 0.0;
+      CK(RUN(initialization_converged, converged_tol, 200000, &sweeps, &res));
+      std::printf("      Poisson-Boltzmann start-up: %d sweeps, relative residual %.2e\n", sweeps, res);
+    } else {
+      CK(RUN(initialization));
+    }
     t = 0.0;
   }
   CK(RUN(set_time, t));

@@ -265,6 +265,26 @@ def test_binary_state_is_lossless(pkg, O, tmp_path):
             s.read_state(path)                   # written for a different lattice
 
 
+def test_cpp_driver_converged_start_on_a_tall_channel(pkg, tmp_path):
+    """The reference's initialization() - 501 Picard sweeps with PB_omega = 0.05, LBM.cu:89-106 - diverges to NaN on channels
+    taller than about 180 planes at the default spacing (the reference itself would, too); `ekpnp_main --converged-init TOL`
+    starts from ekpnp_initialization_converged instead, also over a group of slabs."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "ek-pnp-3d_amd", "ekpnp_main")
+    if not os.path.exists(exe):
+        pytest.skip("ekpnp_main not built")
+    geo = ["--nx", "16", "--ny", "8", "--nz", "257", "--steps", "12", "--print-current", "5"]
+    bad = subprocess.run([exe, *geo, "--out", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 0 and "Current = nan" in bad.stdout.replace("-nan", "nan"), bad.stdout[-500:]
+    for extra in ([], ["--devices", "0,0"]):
+        ok = subprocess.run([exe, *geo, "--converged-init", "1e-9", "--out", str(tmp_path), *extra], capture_output=True, text=True, timeout=300)
+        assert ok.returncode == 0, ok.stderr
+        assert "Poisson-Boltzmann start-up:" in ok.stdout and "nan" not in ok.stdout.lower(), ok.stdout[-800:]
+        cur = [float(l.split("Current = ")[1]) for l in ok.stdout.splitlines() if "Current = " in l]
+        assert len(cur) == 2 and all(np.isfinite(cur)) and all(abs(c) > 0 for c in cur)
+
+
 def test_a_rejected_kernel_launch_is_reported_by_name(tmp_path):
     """Every launch is checked (note_launch): the entry point returns EKPNP_ERR_HIP and
     ekpnp_last_error names the kernel.  Driven by the library's fault-injection knob in a child

@@ -282,7 +282,7 @@ def test_cpp_driver_converged_start_on_a_tall_channel(pkg, tmp_path):
         assert ok.returncode == 0, ok.stderr
         assert "Poisson-Boltzmann start-up:" in ok.stdout and "nan" not in ok.stdout.lower(), ok.stdout[-800:]
         cur = [float(l.split("Current = ")[1]) for l in ok.stdout.splitlines() if "Current = " in l]
-        assert len(cur) == 2 and all(np.isfinite(cur)) and all(abs(c) > 0 for c in cur)
+        assert len(cur) == 3 and all(np.isfinite(cur)) and all(abs(c) > 0 for c in cur)
 
 
 def test_a_rejected_kernel_launch_is_reported_by_name(tmp_path):

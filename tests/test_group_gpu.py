@@ -472,11 +472,15 @@ def test_interior_rank_at_cfg5_width_vs_oracle(pkg, O):
         assert abs(g.umax() - um) <= 1e-6 * abs(um) + 1e-30
 
 
-def test_cfg4_planes_decomposed_over_8_slabs_equal_one_context(pkg, O):
+@pytest.mark.parametrize("shape", [(512, 512, 768), (1024, 1024, 128)])
+def test_cfg4_planes_decomposed_over_8_slabs_equal_one_context(pkg, O, shape):
     """cfg4's full 512 x 512 planes as a DECOMPOSITION at (nearly) full height: 512 x 512 x 768 in 8 in-place slabs of 96
     planes next to each other on the one GPU (201 M nodes, the most that fits beside the halo buffers; cfg4@8's slabs have
     128 planes) against the same lattice in ONE in-place context - same perturbed x-y-z dependent start, 5 steps.  The
-    single context itself is pinned to the oracle at this width by test_full_size_vs_oracle[cfg3_width]."""
+    single context itself is pinned to the oracle at this width by test_full_size_vs_oracle[cfg3_width].
+    And cfg5's 1024 x 1024 planes over EIGHT slabs (six of them interior, as in cfg5@8) at an eighth of the height:
+    1024 x 1024 x 128 in 8 in-place slabs of 16 planes (own plane transforms, four modes per wavefront in the z solve,
+    302 MB halo messages) against one context."""
     import importlib.util
     import torch
 
@@ -485,7 +489,7 @@ def test_cfg4_planes_decomposed_over_8_slabs_equal_one_context(pkg, O):
     spec = importlib.util.spec_from_file_location("group_overhead", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "group_overhead.py"))
     go = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(go)
-    p = pkg.default_params(512, 512, 768)
+    p = pkg.default_params(*shape)
     p.in_place = 1
     keys = ("rho", "c", "cn", "phi", "T", "ux", "uy", "uz", "Ez")
     with pkg.Solver(p) as s:

@@ -181,26 +181,39 @@ static int xev_slot(Team& T, int x, int i, Team::XEv** out) {
   return EKPNP_OK;
 }
 
+// The EDGE and PHI exchanges sit on the critical path of the Poisson solve: nothing runs beside them, so a hop to the comm
+// stream and back (two event hand-overs, ~40 us each way) buys nothing.  Over RCCL they are issued on the slab's COMPUTE
+// stream itself (stream order replaces the events); the population halo keeps its comm stream - that is where the overlap
+// is.  Device-copy groups keep the comm stream for all three (their copies write into the partners' buffers, which the
+// events guard).  EKPNP_INLINE_EXCHANGES=0 is the A/B partner.
+static inline bool inline_exchange(const Team& T, int x) {
+  static const bool on = !(std::getenv("EKPNP_INLINE_EXCHANGES") && std::atoi(std::getenv("EKPNP_INLINE_EXCHANGES")) == 0);
+  return on && T.kind == EKPNP_TRANSPORT_RCCL && x != X_HALO;
+}
+
 // start exchange x: everything the slabs have enqueued so far on their compute streams precedes it
 static int exchange_begin(Team& T, int x) {
   const int n = (int)T.m.size();
+  const bool inl = inline_exchange(T, x);
+  auto xs = [&](int i) { return inl ? S(T, i).stream : T.cs[i]; };  // the stream slab i's part of the exchange runs on
   int rc;
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n && !inl; ++i) {
     if ((rc = use(T, i))) return rc;
     THIP(T, hipEventRecord(T.ready[x][i], S(T, i).stream));
   }
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
-    THIP(T, hipStreamWaitEvent(T.cs[i], T.ready[x][i], 0));
+    if (!inl) THIP(T, hipStreamWaitEvent(T.cs[i], T.ready[x][i], 0));
     if (T.kind == EKPNP_TRANSPORT_COPY) {  // slab i's copies write into its partners' receive buffers
       hipError_t e = hipSuccess;
       for_partners(T, i, x, [&](int j) { if (e == hipSuccess) e = hipStreamWaitEvent(T.cs[i], T.ready[x][j], 0); });
       THIP(T, e);
     }
-    if (S(T, i).timing) {  // the comm stream gets here when this slab's (and its partners') buffers are ready
+    if (S(T, i).timing) {  // the stream gets here when this slab's (and its partners') buffers are ready
       Team::XEv* ev = nullptr;
       if ((rc = xev_slot(T, x, i, &ev))) return rc;
-      THIP(T, hipEventRecord(ev->xfer_begin, T.cs[i]));
+      if (inl) THIP(T, hipEventRecord(ev->wait_begin, xs(i)));  // an inline exchange holds the compute stream for its whole length
+      THIP(T, hipEventRecord(ev->xfer_begin, xs(i)));
     }
   }
   if (T.kind == EKPNP_TRANSPORT_RCCL) {
@@ -211,17 +224,17 @@ static int exchange_begin(Team& T, int x) {
       ncclResult_t r = ncclSuccess;
       if (x == X_EDGE) {
         const size_t per = 4 * (size_t)c.p.ny * c.nxh;
-        r = T.nc->AllGather(c.edge_local, c.edge_all, per, ncclDouble, T.comm[i], T.cs[i]);
+        r = T.nc->AllGather(c.edge_local, c.edge_all, per, ncclDouble, T.comm[i], xs(i));
       } else {
         double** b = x == X_HALO ? c.halo : c.phi_halo;
         const size_t cnt = x == X_HALO ? c.halo_doubles : c.plane;
         const int up = (c.rank + 1) % T.nranks, dn = (c.rank + T.nranks - 1) % T.nranks;
         // order matters when both neighbours are the same peer (2 ranks) or the rank itself (1 rank):
         // [send up, send down] pairs with the peer's [recv from below, recv from above]
-        r = T.nc->Send(b[1], cnt, ncclDouble, up, T.comm[i], T.cs[i]);
-        if (r == ncclSuccess) r = T.nc->Send(b[0], cnt, ncclDouble, dn, T.comm[i], T.cs[i]);
-        if (r == ncclSuccess) r = T.nc->Recv(b[2], cnt, ncclDouble, dn, T.comm[i], T.cs[i]);
-        if (r == ncclSuccess) r = T.nc->Recv(b[3], cnt, ncclDouble, up, T.comm[i], T.cs[i]);
+        r = T.nc->Send(b[1], cnt, ncclDouble, up, T.comm[i], xs(i));
+        if (r == ncclSuccess) r = T.nc->Send(b[0], cnt, ncclDouble, dn, T.comm[i], xs(i));
+        if (r == ncclSuccess) r = T.nc->Recv(b[2], cnt, ncclDouble, dn, T.comm[i], xs(i));
+        if (r == ncclSuccess) r = T.nc->Recv(b[3], cnt, ncclDouble, up, T.comm[i], xs(i));
       }
       if (r != ncclSuccess) {
         (void)T.nc->GroupEnd();
@@ -249,8 +262,12 @@ static int exchange_begin(Team& T, int x) {
   }
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
-    THIP(T, hipEventRecord(T.done[x][i], T.cs[i]));
-    if (S(T, i).timing && T.xev_used[x][i] < T.xev[x][i].size()) THIP(T, hipEventRecord(T.xev[x][i][T.xev_used[x][i]].xfer_end, T.cs[i]));
+    if (!inl) THIP(T, hipEventRecord(T.done[x][i], T.cs[i]));
+    if (S(T, i).timing && T.xev_used[x][i] < T.xev[x][i].size()) {
+      Team::XEv& ev = T.xev[x][i][T.xev_used[x][i]];
+      THIP(T, hipEventRecord(ev.xfer_end, xs(i)));
+      if (inl) THIP(T, hipEventRecord(ev.wait_end, xs(i)));
+    }
   }
   return EKPNP_OK;
 }
@@ -259,6 +276,11 @@ static int exchange_begin(Team& T, int x) {
 static int exchange_finish(Team& T, int x) {
   const int n = (int)T.m.size();
   int rc;
+  if (inline_exchange(T, x)) {  // already in stream order; only the measurement's bookkeeping is left
+    for (int i = 0; i < n; ++i)
+      if (S(T, i).timing && T.xev_used[x][i] < T.xev[x][i].size()) T.xev_used[x][i]++;
+    return EKPNP_OK;
+  }
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
     // measurement: the time the compute stream spends between these two events is the time it had nothing to do but

@@ -1,7 +1,7 @@
 """Diagnostic: growth of the HIP-vs-oracle difference over a long run (16x12x17, 4 lattices)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as G
 pkg = G.load_package(); O = G.load_oracle()
 po = O.default_params(16, 12, 17); po.pb_iterations = 60

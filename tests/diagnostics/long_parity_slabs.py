@@ -2,7 +2,7 @@
 single-context run and the oracle, 24x8x33 (uneven slabs), 4 lattices, up to 3000 steps."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as G
 pkg = G.load_package(); O = G.load_oracle()
 shape = (24, 8, 33)

@@ -2,7 +2,7 @@
 reference's OWN kernels on the same GPU (oracle/_ref/ref_driver_<grid> time <steps>, built by
 oracle/build_ref.sh <grid>).  Same physics (reference defaults), same start (initialization + init_equilibrium)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as G
 pkg = G.load_package()
 nx, ny, nz = (int(v) for v in sys.argv[1].split("x"))

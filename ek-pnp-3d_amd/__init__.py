@@ -23,4 +23,5 @@ from .solver import (  # noqa: F401
     exported_symbols,
     library_path,
     load_library,
+    slab_extent,
 )

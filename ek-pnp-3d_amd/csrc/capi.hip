@@ -88,6 +88,12 @@ extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
   if (std::strcmp(knob, "ab_zchunk") == 0 && value >= 0) { c.ab_zchunk = value; return EKPNP_OK; }
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
+  if (std::strcmp(knob, "lazy_efield") == 0 && (value == 0 || value == 1)) {  // the A/B partner of the EPHI kernels: 0 = k_phi_efield in every solve
+    const int rc = ensure_efield(c);
+    c.lazy_efield = value;
+    drop_graph(c);
+    return rc;
+  }
   c.err = "ekpnp_tune: unknown knob or bad value";
   return EKPNP_ERR_INVALID;
 }
@@ -97,6 +103,32 @@ extern "C" int ekpnp_debug_sync_enabled(void) { return std::getenv("EKPNP_DEBUG_
 static void drop_graph(Ctx& c) {
   if (c.graph2) { (void)hipGraphExecDestroy(c.graph2); c.graph2 = nullptr; }
   c.graph_cur = -1;
+}
+
+// ---- lazy E (round 4; Ctx::e_stale) -------------------------------------------------------------------------------
+namespace ekpnp {
+bool lazy_efield_ok(const Ctx& c) {
+  return c.lazy_efield != 0 && c.p.n_lattices > 1 && !c.e_exposed && c.fld_owned[EKPNP_PHI] && c.fld_owned[EKPNP_EX] &&
+         c.fld_owned[EKPNP_EY] && c.fld_owned[EKPNP_EZ];
+}
+int ensure_efield(Ctx& c) {
+  if (!c.e_stale) return EKPNP_OK;
+  launch_phi_efield(c);  // odd_extract's plates + gpu_efield + gpu_bc (poisson.cu:40-69,198-203) from the phi the last solve left
+  c.e_stale = false;
+  LAUNCHCHK(c);
+  return EKPNP_OK;
+}
+int efield_set_from_outside(Ctx& c) {
+  int rc = ensure_efield(c);  // a caller that sets ONE of phi / Ex / Ey / Ez finds the other three as the reference would have them
+  c.e_phi_valid = false;
+  return rc;
+}
+}  // namespace ekpnp
+static inline bool is_phi_or_e(int id) { return id == EKPNP_PHI || id == EKPNP_EX || id == EKPNP_EY || id == EKPNP_EZ; }
+// the state a solve leaves behind: lazily (E lives in phi until somebody looks) or with the arrays written
+static inline void mark_solved(Ctx& c, bool lazy) {
+  c.e_stale = lazy;
+  c.e_phi_valid = true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -174,6 +206,9 @@ KArgs Ctx::kargs() const {
   a.eps = p.eps;
   a.rhs_wall_lo = p.voltage / p.dz / p.dz;    // poisson.cu:124
   a.rhs_wall_hi = p.voltage2 / p.dz / p.dz;   // poisson.cu:134
+  a.phi_lo = phi_halo[2]; a.phi_hi = phi_halo[3];
+  a.voltage = p.voltage; a.voltage2 = p.voltage2;
+  a.dx = p.dx; a.dy = p.dy; a.dz = p.dz;
   return a;
 }
 
@@ -266,6 +301,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.tri_lds_ok = tridiag_prepare_device();
   if (const char* e = std::getenv("EKPNP_BULK_ZCHUNK")) c.ab_zchunk = std::atoi(e) > 0 ? std::atoi(e) : 0;
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
+  if (const char* e = std::getenv("EKPNP_LAZY_E")) c.lazy_efield = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("EKPNP_TRI_PARTITION")) c.tri_partition = std::atoi(e) < 0 ? 0 : (std::atoi(e) > 2 ? 2 : std::atoi(e));
   // In-place mode: one buffer per lattice with `shift` spare planes.  A sweep writes plane z of
   // the new state `shift` planes below (parity 0, bulk launches of `zchunk` planes in ascending z)
@@ -469,6 +505,7 @@ extern "C" int ekpnp_set_stream(ekpnp_ctx* ctx, void* s) {
 
 extern "C" int ekpnp_synchronize(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
+  if (int rc = ensure_efield(c)) return rc;  // "complete" includes the Ex / Ey / Ez arrays a lazy solve left behind
   HIPCHK(c, hipStreamSynchronize(c.stream));
   LAUNCHCHK(c);
   return EKPNP_OK;
@@ -477,6 +514,9 @@ extern "C" int ekpnp_synchronize(ekpnp_ctx* ctx) {
 extern "C" int ekpnp_bind_field(ekpnp_ctx* ctx, int id, double* dptr) {
   NEEDCTX(ctx);
   if (id < 0 || id >= EKPNP_NFIELDS || !dptr) return fail(c, "bad field id or NULL pointer");
+  if (is_phi_or_e(id)) {  // a caller-owned phi / E array is written by every solve, as the reference writes its own (eager path)
+    if (int rc = ensure_efield(c)) return rc;
+  }
   HIPCHK(c, hipStreamSynchronize(c.stream));
   HIPCHK(c, hipMemcpy(dptr, c.fld[id], c.nloc * sizeof(double), hipMemcpyDeviceToDevice));
   if (c.fld_owned[id]) {
@@ -495,6 +535,12 @@ extern "C" int ekpnp_bind_field(ekpnp_ctx* ctx, int id, double* dptr) {
 extern "C" int ekpnp_field_device_ptr(ekpnp_ctx* ctx, int id, double** dptr) {
   NEEDCTX(ctx);
   if (id < 0 || id >= EKPNP_NFIELDS || !dptr) return fail(c, "bad field id or NULL pointer");
+  if (is_phi_or_e(id)) {
+    // whoever holds this pointer may read - or write - phi / E on the device between any two calls: from here on every
+    // solve writes them (the eager path of rounds 1-3), and the collide reads the arrays
+    if (int rc = ensure_efield(c)) return rc;
+    if (!c.e_exposed) { c.e_exposed = true; drop_graph(c); }
+  }
   *dptr = c.fld[id];
   return EKPNP_OK;
 }
@@ -502,6 +548,9 @@ extern "C" int ekpnp_field_device_ptr(ekpnp_ctx* ctx, int id, double** dptr) {
 extern "C" int ekpnp_set_field(ekpnp_ctx* ctx, int id, const double* host) {
   NEEDCTX(ctx);
   if (id < 0 || id >= EKPNP_NFIELDS || !host) return fail(c, "bad field id or NULL pointer");
+  if (is_phi_or_e(id)) {
+    if (int rc = efield_set_from_outside(c)) return rc;
+  }
   HIPCHK(c, hipStreamSynchronize(c.stream));
   HIPCHK(c, hipMemcpy(c.fld[id], host, c.nloc * sizeof(double), hipMemcpyHostToDevice));
   c.rhs_ready = false;
@@ -511,6 +560,9 @@ extern "C" int ekpnp_set_field(ekpnp_ctx* ctx, int id, const double* host) {
 extern "C" int ekpnp_get_field(ekpnp_ctx* ctx, int id, double* host) {
   NEEDCTX(ctx);
   if (id < 0 || id >= EKPNP_NFIELDS || !host) return fail(c, "bad field id or NULL pointer");
+  if (is_phi_or_e(id)) {
+    if (int rc = ensure_efield(c)) return rc;
+  }
   HIPCHK(c, hipStreamSynchronize(c.stream));
   HIPCHK(c, hipMemcpy(host, c.fld[id], c.nloc * sizeof(double), hipMemcpyDeviceToHost));
   return EKPNP_OK;
@@ -593,7 +645,9 @@ static int poisson_timing_mark(Ctx& c, bool begin) {
   return EKPNP_OK;
 }
 
-static int poisson_single(Ctx& c) {
+// allow_lazy: the solve may leave E in phi (time loop, ekpnp_fast_poisson).  The Poisson-Boltzmann start-up passes false:
+// its kernels read and relax phi on the plates too (LBM.cu:98-104,131-146), so every sweep pins them like odd_extract does.
+static int poisson_single(Ctx& c, bool allow_lazy) {
   int trc = poisson_timing_mark(c, true);
   if (trc) return trc;
   if (!c.rhs_ready) launch_poisson_rhs(c);
@@ -601,7 +655,9 @@ static int poisson_single(Ctx& c) {
   if (int frc = plane_fft_forward(c)) return frc;
   launch_tridiag(c);
   if (int frc = plane_fft_inverse(c)) return frc;
-  launch_phi_efield(c);
+  const bool lazy = allow_lazy && lazy_efield_ok(c);
+  if (!lazy) launch_phi_efield(c);
+  mark_solved(c, lazy);
   LAUNCHCHK(c);
   return poisson_timing_mark(c, false);
 }
@@ -618,7 +674,7 @@ extern "C" int ekpnp_fast_poisson(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   distrust_bound_rhs(c);
   if (c.slab) return c.team ? team_ctx_fast_poisson(c) : fail(c, "ekpnp_fast_poisson on a slab context without a transport: attach one (ekpnp_slab_attach_comm), use ekpnp_group_*, or drive ekpnp_poisson_stage1/2/3 yourself");
-  return poisson_single(c);
+  return poisson_single(c, true);
 }
 
 extern "C" int ekpnp_invalidate_rhs(ekpnp_ctx* ctx) {
@@ -633,6 +689,8 @@ extern "C" int ekpnp_invalidate_rhs(ekpnp_ctx* ctx) {
 extern "C" int ekpnp_init_fields(ekpnp_ctx* ctx) {  // gpu_initialization, LBM.cu:111-128
   NEEDCTX(ctx);
   c.rhs_ready = false;
+  c.e_stale = false;      // every array is written here: phi = voltage, E = 0 (LBM.cu:111-128)
+  c.e_phi_valid = false;
   launch_init_fields(c);
   LAUNCHCHK(c);
   return EKPNP_OK;
@@ -640,6 +698,7 @@ extern "C" int ekpnp_init_fields(ekpnp_ctx* ctx) {  // gpu_initialization, LBM.c
 
 extern "C" int ekpnp_pbe_begin(ekpnp_ctx* ctx) {  // LBM.cu:79-86: phi_old <- phi
   NEEDCTX(ctx);
+  if (int rc = ensure_efield(c)) return rc;  // phi_old takes the plates too
   if (!c.phi_old) HIPCHK(c, hipMalloc((void**)&c.phi_old, c.nloc * sizeof(double)));
   HIPCHK(c, hipMemcpyAsync(c.phi_old, c.fld[EKPNP_PHI], c.nloc * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
   return EKPNP_OK;
@@ -647,6 +706,7 @@ extern "C" int ekpnp_pbe_begin(ekpnp_ctx* ctx) {  // LBM.cu:79-86: phi_old <- ph
 
 extern "C" int ekpnp_pbe_concentrations(ekpnp_ctx* ctx) {  // gpu_PBE, LBM.cu:139-146
   NEEDCTX(ctx);
+  if (int rc = ensure_efield(c)) return rc;  // reads phi on every plane, the plates included
   c.rhs_ready = false;
   launch_pbe(c);
   LAUNCHCHK(c);
@@ -656,6 +716,7 @@ extern "C" int ekpnp_pbe_concentrations(ekpnp_ctx* ctx) {  // gpu_PBE, LBM.cu:13
 extern "C" int ekpnp_pbe_relax(ekpnp_ctx* ctx) {  // gpu_PBE_phi + phi_old update, LBM.cu:98-104
   NEEDCTX(ctx);
   if (!c.phi_old) return fail(c, "ekpnp_pbe_relax without ekpnp_pbe_begin");
+  if (int rc = efield_set_from_outside(c)) return rc;  // phi is relaxed on every plane: E no longer derives from it
   launch_pbe_relax(c, c.phi_old, c.p.PB_omega);
   LAUNCHCHK(c);
   return EKPNP_OK;
@@ -665,6 +726,7 @@ extern "C" int ekpnp_pbe_end(ekpnp_ctx* ctx) {  // LBM.cu:107-108
   NEEDCTX(ctx);
   HIPCHK(c, hipStreamSynchronize(c.stream));
   if (c.phi_old) { (void)hipFree(c.phi_old); c.phi_old = nullptr; }
+  c.e_phi_valid = false;  // phi was relaxed after the last solve formed E (LBM.cu:96-104): E is what the arrays say
   return EKPNP_OK;
 }
 
@@ -676,8 +738,9 @@ extern "C" int ekpnp_initialization(ekpnp_ctx* ctx) {
   for (int i = 0; rc == EKPNP_OK && i < c.p.pb_iterations; ++i) {  // LBM.cu:89-106
     c.rhs_ready = false;
     launch_pbe(c);
-    rc = poisson_single(c);
+    rc = poisson_single(c, false);
     launch_pbe_relax(c, c.phi_old, c.p.PB_omega);
+    c.e_phi_valid = false;  // the relaxed phi is not the phi E was taken from (LBM.cu:96-104: efield runs inside fast_Poisson, before gpu_PBE_phi)
   }
   int rc2 = ekpnp_pbe_end(ctx);
   if (rc == EKPNP_OK) rc = rc2;
@@ -712,12 +775,13 @@ extern "C" int ekpnp_initialization_converged(ekpnp_ctx* ctx, double rel_tol, in
   while (rc == EKPNP_OK && done < max_sweeps) {
     c.rhs_ready = false;
     launch_pbe(c);
-    rc = poisson_single(c);
+    rc = poisson_single(c, false);
     if (rc) break;
     ++done;
     const bool check = (done % check_every == 0) || done == max_sweeps;
     if (check) launch_max_abs_diff(c, c.fld[EKPNP_PHI], c.phi_old, c.diag);
     launch_pbe_relax(c, c.phi_old, omega);
+    c.e_phi_valid = false;
     if (check) {
       double r = 0.0;
       hipError_t e = hipMemcpyAsync(&r, c.diag + 1024, sizeof(double), hipMemcpyDeviceToHost, c.stream);
@@ -737,6 +801,7 @@ extern "C" int ekpnp_initialization_converged(ekpnp_ctx* ctx, double rel_tol, in
 
 extern "C" int ekpnp_init_equilibrium(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
+  if (int rc = ensure_efield(c)) return rc;  // the equilibria drift with u + K E (LBM.cu:207-462): the E arrays are read
   launch_init_equilibrium(c);
   c.streamed_state = true;
   LAUNCHCHK(c);
@@ -826,7 +891,8 @@ static int placement_search(Ctx& c, size_t pitch, int nbuf) {
   HIPCHK(c, hipEventCreate(&e1));
   auto point_at = [&](void* base) { carve_arena(c, base, pitch); };
   const bool streamed0 = c.streamed_state;
-  c.streamed_state = false;  // time the kernel the steps run: pull + collide
+  c.streamed_state = false;  // time the kernel the steps run: pull + collide,
+  c.e_phi_valid = lazy_efield_ok(c);  // E from phi (all zero here) where the steps will take it from phi
   int n = 0;
   hipError_t e = hipSuccess;
   for (; n < tries && e == hipSuccess; ++n) {
@@ -860,6 +926,7 @@ static int placement_search(Ctx& c, size_t pitch, int nbuf) {
   c.pop_alloc[0][0] = cand[pick];
   point_at(cand[pick]);
   c.streamed_state = streamed0;
+  c.e_phi_valid = false;
   c.cur = 0;
   c.rhs_ready = false;
   c.placement_tries = n;
@@ -938,7 +1005,7 @@ static int one_step(ekpnp_ctx* ctx) {  // main.cu:189-200
   Ctx& c = ctx->c;
   int rc = ekpnp_stream_collide_save(ctx, c.t);
   if (rc) return rc;
-  rc = poisson_single(c);
+  rc = poisson_single(c, true);
   if (rc) return rc;
   c.t = c.t + c.p.dt;
   return EKPNP_OK;
@@ -958,6 +1025,7 @@ static int capture_two_steps(ekpnp_ctx* ctx) {
   drop_graph(c);
   const int cur0 = c.cur;
   const double t0 = c.t;
+  const bool stale0 = c.e_stale, phiv0 = c.e_phi_valid;
   if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); c.graph_failed = true; return EKPNP_OK; }
   int rc = one_step(ctx);
   if (rc == EKPNP_OK) rc = one_step(ctx);
@@ -967,6 +1035,8 @@ static int capture_two_steps(ekpnp_ctx* ctx) {
   c.cur = cur0;
   c.t = t0;
   c.rhs_ready = false;
+  c.e_stale = stale0;
+  c.e_phi_valid = phiv0;
   if (rc != EKPNP_OK || e != hipSuccess || !g) {
     (void)hipGetLastError();
     if (g) (void)hipGraphDestroy(g);
@@ -986,7 +1056,9 @@ extern "C" int ekpnp_step(ekpnp_ctx* ctx, int nsteps) {
   if (nsteps < 0) return fail(c, "nsteps < 0");
   if (c.slab) return c.team ? team_ctx_step(c, nsteps) : fail(c, "slab context without a transport: attach one, use ekpnp_group_*, or drive the split calls yourself");
   int i = 0;
-  if (c.streamed_state && nsteps > 0) {  // the first step after init_equilibrium does not pull
+  // the first step after init_equilibrium does not pull; one whose E was set from outside reads the E arrays: neither is
+  // the step the graph below captures
+  if ((c.streamed_state || (lazy_efield_ok(c) && !c.e_phi_valid)) && nsteps > 0) {
     int rc = one_step(ctx);
     if (rc) return rc;
     ++i;
@@ -998,6 +1070,7 @@ extern "C" int ekpnp_step(ekpnp_ctx* ctx, int nsteps) {
     }
     while (c.graph2 && nsteps - i >= 2) {
       HIPCHK(c, hipGraphLaunch(c.graph2, c.stream));
+      mark_solved(c, lazy_efield_ok(c));
       c.t = c.t + c.p.dt;
       c.t = c.t + c.p.dt;
       i += 2;
@@ -1204,7 +1277,11 @@ extern "C" int ekpnp_phi_halo_pack(ekpnp_ctx* ctx) {
 extern "C" int ekpnp_poisson_stage3(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
-  launch_phi_efield(c);
+  // the phi planes of the neighbouring slabs have arrived (PHI exchange): either E is written now, or the next collide
+  // forms it from phi and these very halo planes (which the next PHI exchange only overwrites after that collide)
+  const bool lazy = c.phi_old == nullptr && lazy_efield_ok(c);  // not inside the Poisson-Boltzmann sweeps (ekpnp_pbe_begin .. ekpnp_pbe_end), see poisson_single
+  if (!lazy) launch_phi_efield(c);
+  mark_solved(c, lazy);
   LAUNCHCHK(c);
   return poisson_timing_mark(c, false);
 }

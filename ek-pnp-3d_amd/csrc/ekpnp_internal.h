@@ -90,6 +90,11 @@ struct KArgs {
   double* rhs;                 // [nzl][ny][nx] or null
   double eps;
   double rhs_wall_lo, rhs_wall_hi;  // voltage/dz/dz (plane 1), voltage2/dz/dz (plane nz-2)
+  // E taken from phi inside the collide (EPHI kernels, round 4): gpu_efield / gpu_bc (poisson.cu:40-69) evaluated
+  // where E is consumed, with the expression of k_phi_efield, so the Ex / Ey / Ez arrays need not be written per step
+  const double* phi_lo;        // phi plane below / above the slab (slab contexts), or null
+  const double* phi_hi;
+  double voltage, voltage2, dx, dy, dz;
 };
 
 // Right-hand side of the Poisson equation on an interior plane, odd_extension's rows 1..NZ-2
@@ -189,6 +194,14 @@ struct Ctx {
   int placement_tries = 0, placement_chosen = 0;  // placement_search (capi.hip): arenas timed at creation, the one kept
   double placement_ms[8] = {};                    // their best sweep times
   bool rhs_ready = false;      // work[] holds the Poisson rhs of the current c, cn (written by the collide)
+  // Lazy E (round 4).  A solve inside the time loop leaves phi's interior planes in the phi array and does NOT run
+  // k_phi_efield: the next collide takes E = central differences of phi itself (EPHI kernels, same expression, same
+  // bits), and the Ex / Ey / Ez arrays and the pinned plates of phi are brought up to date only when somebody looks
+  // (ensure_efield: get_field, writers, diagnostics, ekpnp_synchronize ...).
+  bool e_stale = false;        // the E arrays and phi's plates are older than phi's interior (implies e_phi_valid)
+  bool e_phi_valid = false;    // E == central differences of the phi array (true after every solve, false once E or phi were set from outside)
+  bool e_exposed = false;      // ekpnp_field_device_ptr handed out phi / E: the caller may read or write them at any time -> eager from then on
+  int lazy_efield = 1;         // knob (EKPNP_LAZY_E, ekpnp_tune "lazy_efield"): 0 = k_phi_efield in every solve, as in rounds 1-3
   bool streamed_state = true;  // true: pop[cur] holds X1 (post-stream, e.g. fresh equilibrium);
                                // false: pop[cur] holds post-collision populations (pull next)
   double* fld[EKPNP_NFIELDS] = {};
@@ -248,6 +261,13 @@ struct Ctx {
   KArgs kargs() const;
   PArgs pargs() const;
 };
+
+// capi.hip: may this context leave E in phi (every one of phi, Ex, Ey, Ez is the library's own, unexposed array)?
+bool lazy_efield_ok(const Ctx& c);
+// capi.hip: bring the E arrays and phi's plates up to date if a lazy solve left them behind (no-op otherwise)
+int ensure_efield(Ctx& c);
+// capi.hip: phi or E are about to be overwritten from outside (set_field, readers): up to date first, then E is what the arrays say
+int efield_set_from_outside(Ctx& c);
 
 // Called after EVERY kernel launch of the library: a launch that the runtime rejects (bad grid,
 // missing code object ...) is recorded with the kernel's name instead of surfacing, nameless, at the

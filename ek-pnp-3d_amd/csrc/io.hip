@@ -48,6 +48,7 @@ extern "C" int ekpnp_current(ekpnp_ctx* ctx, double* I) {
     if (c.nzl < 3) return fail(c, "the upper slab needs 3 planes for the wall extrapolation");
     int rc = need_scratch(c);
     if (rc) return rc;
+    if ((rc = ensure_efield(c))) return rc;  // reads the Ez array
     launch_current(c, c.diag);
     if (take_launch_error(c) != hipSuccess) return EKPNP_ERR_HIP;
     double s = 0.0;
@@ -90,6 +91,7 @@ extern "C" int ekpnp_record_umax(ekpnp_ctx* ctx, const char* path, int append, d
 // of rho, c, cn, u on the plates it holds (LBM.cu:2527-2542 / 2596-2611); planes 0..2 and
 // NZ-3..NZ-1 always lie inside one slab (a slab has at least 4 planes)
 static int fetch_fields(Ctx& c, std::vector<std::vector<double>>& h, bool extrapolate) {
+  if (int rc = ensure_efield(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c.stream));
   h.assign(EKPNP_NFIELDS, std::vector<double>(c.nloc));
   for (int i = 0; i < EKPNP_NFIELDS; ++i) HIPCHK(c, hipMemcpy(h[i].data(), c.fld[i], c.nloc * sizeof(double), hipMemcpyDeviceToHost));
@@ -158,6 +160,7 @@ int io_read_data_part(Ctx& c, const char* path, double* time) {
                      &h[EKPNP_T][i]) == 12;
   std::fclose(f);
   if (!ok) return fail(c, "restart file is shorter than the lattice or malformed");
+  if (int rc = efield_set_from_outside(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c.stream));
   for (int i = 0; i < EKPNP_NFIELDS; ++i) HIPCHK(c, hipMemcpy(c.fld[i], h[i].data(), c.nloc * sizeof(double), hipMemcpyHostToDevice));
   c.t = *time;
@@ -221,6 +224,7 @@ extern "C" int ekpnp_save_state(ekpnp_ctx* ctx, const char* path, double time) {
   h.time = time;
   bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
   std::vector<double> buf(c.nloc < STATE_CHUNK ? c.nloc : STATE_CHUNK);
+  if (ensure_efield(c) != EKPNP_OK) { std::fclose(f); return EKPNP_ERR_HIP; }
   hipError_t e = hipStreamSynchronize(c.stream);
   for (int i = 0; ok && e == hipSuccess && i < EKPNP_NFIELDS; ++i)
     for (size_t o = 0; ok && e == hipSuccess && o < c.nloc; o += buf.size()) {
@@ -249,6 +253,7 @@ extern "C" int ekpnp_read_state(ekpnp_ctx* ctx, const char* path, double* time) 
   }
   std::vector<double> buf(c.nloc < STATE_CHUNK ? c.nloc : STATE_CHUNK);
   bool ok = true;
+  if (efield_set_from_outside(c) != EKPNP_OK) { std::fclose(f); return EKPNP_ERR_HIP; }
   hipError_t e = hipStreamSynchronize(c.stream);
   for (int i = 0; ok && e == hipSuccess && i < EKPNP_NFIELDS; ++i)
     for (size_t o = 0; ok && e == hipSuccess && o < c.nloc; o += buf.size()) {
@@ -302,7 +307,11 @@ int io_stream_device(Ctx& c, FILE* f, double* dev, size_t n, int dir) {
   return EKPNP_OK;
 }
 
-int io_ckpt_fields(Ctx& c, FILE* f, int field, int dir) { return io_stream_device(c, f, c.fld[field], c.nloc, dir); }
+int io_ckpt_fields(Ctx& c, FILE* f, int field, int dir) {
+  if (int rc = dir == 0 ? ensure_efield(c) : efield_set_from_outside(c)) return rc;
+  if (dir == 0) HIPCHK(c, hipStreamSynchronize(c.stream));
+  return io_stream_device(c, f, c.fld[field], c.nloc, dir);
+}
 
 // owned planes zg = 1..nzl of lattice l's current state (with_ghosts: zg = 0..nzl+1)
 int io_ckpt_populations(Ctx& c, FILE* f, int l, int with_ghosts, int dir) {
@@ -388,6 +397,7 @@ extern "C" int ekpnp_save_scalar(ekpnp_ctx* ctx, const char* name, int field_id,
   std::snprintf(format, sizeof format, "%%s%%0%dd.bin", ndigits);                        // LBM.cu:2465
   std::snprintf(filename, sizeof filename, format, name, n);
   std::vector<double> h(c.nloc);
+  if (int rc = ensure_efield(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c.stream));
   HIPCHK(c, hipMemcpy(h.data(), c.fld[field_id], c.nloc * sizeof(double), hipMemcpyDeviceToHost));
   FILE* f = std::fopen(filename, "wb");

@@ -156,9 +156,14 @@ __device__ __forceinline__ void equilibrium(const KArgs& a, double m, double vx,
 #define EKPNP_BULK_MIN_WAVES 1  // tuning knob: min waves per SIMD the register allocator must allow
 #endif
 // the work of one bulk workgroup: row `row` of the launch (y = row % ny, plane zl_begin + row / ny), x block xb
-template <int NL, bool PULL>
+// EPHI: E is not read from the Ex / Ey / Ez arrays but formed from phi right here - gpu_efield's central differences
+// (poisson.cu:45-55) in the expression of k_phi_efield, 0.5*(a - b)/d, hence the same bits -, one component per wave
+// (h: Ex, hn: Ey, temp - or f when there is no temperature lattice - Ez), shared through three more rows of the moment
+// image.  The kernel then reads phi(y-1), phi(y), phi(y+1), phi(z-1), phi(z+1): 24 bytes per node of HBM traffic like
+// the three E arrays (the y neighbours are L2 hits), and k_phi_efield (8 R + 24 W per node) drops out of the step.
+template <int NL, bool PULL, bool EPHI>
 __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, const int row, const int xb) {
-  __shared__ double mom[7][64];
+  __shared__ double mom[EPHI ? 10 : 7][64];
   const int y = row % a.ny;
   const int zl = zl_begin + row / a.ny;
   const int zg = zl + 1;
@@ -185,6 +190,26 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
   });
 
   if constexpr (NL > 1) {
+    if constexpr (EPHI) {
+      constexpr int ZLAT = NL > 3 ? 3 : 0;  // the wave that forms Ez
+      const double* __restrict__ ph = a.fld[EKPNP_PHI] + (long long)zl * a.plane;
+      if (lat == 1) {
+        const double* __restrict__ r = ph + (long long)y * a.nx;
+        const double pl = r[xc == 0 ? a.nx - 1 : xc - 1], pr = r[xc + 1 == a.nx ? 0 : xc + 1];
+        mom[7][lane] = 0.5 * (pl - pr) / a.dx;
+      } else if (lat == 2) {
+        const double pl = ph[(long long)ys[2] * a.nx + xc], pr = ph[(long long)ys[0] * a.nx + xc];
+        mom[8][lane] = 0.5 * (pl - pr) / a.dy;
+      }
+      if (lat == ZLAT) {
+        // phi(z-1), phi(z+1): the plate's pinned value, the neighbouring slab's plane or the array (z is uniform over the workgroup)
+        const int z = a.z0 + zl;
+        const long long oc = (long long)y * a.nx + xc;
+        const double pm = z - 1 <= 0 ? a.voltage : (zl == 0 ? a.phi_lo[oc] : ph[oc - a.plane]);
+        const double pp = z + 1 >= a.nz - 1 ? a.voltage2 : (zl == a.nzl - 1 ? a.phi_hi[oc] : ph[oc + a.plane]);
+        mom[9][lane] = 0.5 * (pm - pp) / a.dz;
+      }
+    }
     if (lat == 0) {
       double jx, jy, jz;
       momentum(f, jx, jy, jz);
@@ -207,9 +232,15 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
     c = mom[4][lane];
     cn = mom[5][lane];
     if constexpr (NL > 3) T = mom[6][lane];
-    Ex = a.fld[EKPNP_EX][sidx];
-    Ey = a.fld[EKPNP_EY][sidx];
-    Ez = a.fld[EKPNP_EZ][sidx];
+    if constexpr (EPHI) {
+      Ex = mom[7][lane];
+      Ey = mom[8][lane];
+      Ez = mom[9][lane];
+    } else {
+      Ex = a.fld[EKPNP_EX][sidx];
+      Ey = a.fld[EKPNP_EY][sidx];
+      Ez = a.fld[EKPNP_EZ][sidx];
+    }
   } else {
     rho = sum27(f);
     momentum(f, jx, jy, jz);
@@ -266,12 +297,12 @@ __device__ __forceinline__ int bulk_row_of_block(const int nrows, const int nxb,
   return row < nrows ? row : -1;
 }
 
-template <int NL, bool PULL>
+template <int NL, bool PULL, bool EPHI>
 __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(const KArgs a, const int zl_begin, const int nrows, const int nxb, const int rchunk) {
   int xb;
   const int row = bulk_row_of_block(nrows, nxb, rchunk, xb);
   if (row < 0) return;  // whole workgroup leaves together
-  bulk_body<NL, PULL>(a, zl_begin, row, xb);
+  bulk_body<NL, PULL, EPHI>(a, zl_begin, row, xb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -314,7 +345,9 @@ __device__ __forceinline__ void wall_scalar_pops(const KArgs& a, int lat, const 
 }
 
 // one wall node: plate `top` (0 lower, 1 upper), node (x, y); one thread, the lattices in sequence
-template <int NL, bool PULL>
+// EPHI (see bulk_body): on a plate phi is constant, so Ex = Ey = +0 (k_phi_efield forms 0.5*(v - v)/d there), and Ez is
+// gpu_bc's copy of the neighbouring interior plane's Ez (poisson.cu:57-69), formed from phi like that plane forms it.
+template <int NL, bool PULL, bool EPHI>
 __device__ __forceinline__ void wall_body(const KArgs& a, const int top, const int x, const int y) {
   const int zl = top ? a.nzl - 1 : 0;
   const int zg = zl + 1;
@@ -343,9 +376,16 @@ __device__ __forceinline__ void wall_body(const KArgs& a, const int top, const i
   }
   double Ex = 0.0, Ey = 0.0, Ez = 0.0;
   if constexpr (NL > 1) {
-    Ex = a.fld[EKPNP_EX][sidx];
-    Ey = a.fld[EKPNP_EY][sidx];
-    Ez = a.fld[EKPNP_EZ][sidx];
+    if constexpr (EPHI) {
+      const double* __restrict__ ph = a.fld[EKPNP_PHI];
+      const long long oc = (long long)y * a.nx + x;
+      // plane 1 / NZ-2: 0.5*(phi(z-1) - phi(z+1))/dz with the plate's pinned value on one side
+      Ez = top ? 0.5 * (ph[(long long)(a.nzl - 3) * a.plane + oc] - a.voltage2) / a.dz : 0.5 * (a.voltage - ph[2 * a.plane + oc]) / a.dz;
+    } else {
+      Ex = a.fld[EKPNP_EX][sidx];
+      Ey = a.fld[EKPNP_EY][sidx];
+      Ez = a.fld[EKPNP_EZ][sidx];
+    }
   }
   const double rhoinv = 1.0 / rho;
   const double hdt = a.dt * 0.5;
@@ -365,9 +405,18 @@ __device__ __forceinline__ void wall_body(const KArgs& a, const int top, const i
       gather<PULL>(a, a.A[2], x, y, zg + 1, g);
       m1[1] = sum27(g);
       const long long s1 = sidx + a.plane;
-      E1x = a.fld[EKPNP_EX][s1];
-      E1y = a.fld[EKPNP_EY][s1];
-      E1z = a.fld[EKPNP_EZ][s1];
+      if constexpr (EPHI) {
+        const double* __restrict__ p1 = a.fld[EKPNP_PHI] + a.plane;  // plane 1
+        const int xm = x == 0 ? a.nx - 1 : x - 1, xp = x + 1 == a.nx ? 0 : x + 1;
+        const int ym = y == 0 ? a.ny - 1 : y - 1, yp = y + 1 == a.ny ? 0 : y + 1;
+        E1x = 0.5 * (p1[(long long)y * a.nx + xm] - p1[(long long)y * a.nx + xp]) / a.dx;
+        E1y = 0.5 * (p1[(long long)ym * a.nx + x] - p1[(long long)yp * a.nx + x]) / a.dy;
+        E1z = Ez;  // Ez(0) is the copy of Ez(1)
+      } else {
+        E1x = a.fld[EKPNP_EX][s1];
+        E1y = a.fld[EKPNP_EY][s1];
+        E1z = a.fld[EKPNP_EZ][s1];
+      }
     }
     if constexpr (NL > 3) {
       gather<PULL>(a, a.A[3], x, y, zg + 1, g);
@@ -426,32 +475,32 @@ __device__ __forceinline__ void wall_body(const KArgs& a, const int top, const i
   }
 }
 
-template <int NL, bool PULL>
+template <int NL, bool PULL, bool EPHI>
 __global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int first_wall) {
   // one launch covers the walls this context owns: blockIdx.z = 0 is wall `first_wall`
   // (0 lower plate, 1 upper plate), blockIdx.z = 1 the upper plate
   const int x = blockIdx.x * 64 + threadIdx.x;
   if (x >= a.nx) return;
-  wall_body<NL, PULL>(a, first_wall + (int)blockIdx.z, x, (int)blockIdx.y);
+  wall_body<NL, PULL, EPHI>(a, first_wall + (int)blockIdx.z, x, (int)blockIdx.y);
 }
 
 // Launch-bound lattices (the reference's own 50x8x51: wall planes 12 us, bulk 10 us, both pure latency):
 // ONE launch for the whole lattice.  The rows beyond the bulk rows are the plates' rows; there the first
 // wave of the workgroup does the wall nodes and the other waves leave (the row, hence the branch, is
 // uniform over the workgroup, so the barrier of the bulk path is never reached by a part of a workgroup).
-template <int NL, bool PULL>
+template <int NL, bool PULL, bool EPHI>
 __global__ void __launch_bounds__(64 * NL) k_collide_all(const KArgs a, const int zl_begin, const int nrows_bulk, const int nxb, const int rchunk) {
   int xb;
   const int row = bulk_row_of_block(nrows_bulk + 2 * a.ny, nxb, rchunk, xb);
   if (row < 0) return;
   if (row < nrows_bulk) {
-    bulk_body<NL, PULL>(a, zl_begin, row, xb);
+    bulk_body<NL, PULL, EPHI>(a, zl_begin, row, xb);
   } else {
     if (threadIdx.x >= 64) return;
     const int w = row - nrows_bulk;  // [0, ny): lower plate, [ny, 2 ny): upper plate
     const int x = xb * 64 + (int)threadIdx.x;
     if (x >= a.nx) return;
-    wall_body<NL, PULL>(a, w / a.ny, x, w % a.ny);
+    wall_body<NL, PULL, EPHI>(a, w / a.ny, x, w % a.ny);
   }
 }
 
@@ -598,6 +647,10 @@ __global__ void k_init_equilibrium(KArgs a) {
 
 static inline dim3 grid1d(long long n, int b) { return dim3((unsigned)((n + b - 1) / b)); }
 
+// the collide forms E from phi (EPHI kernels) whenever phi is known to be what E derives from AND nobody outside can
+// have touched the E arrays since; both sources hold the same bits when both are valid
+static inline bool collide_takes_e_from_phi(const Ctx& c) { return c.p.n_lattices > 1 && c.e_phi_valid && lazy_efield_ok(c); }
+
 void launch_init_fields(Ctx& c) {
   KArgs a = c.kargs();
   hipLaunchKernelGGL(k_init_fields, grid1d((long long)c.nloc, 256), dim3(256), 0, c.stream, a, c.p.voltage, c.p.Lz, c.p.dz);
@@ -638,10 +691,14 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
   // rows per XCD, rounded up to whole runs: the 8 XCDs together cover [0, 8*per_xcd) >= nrows
   const long long per_xcd = ((long long)nrows + 8LL * rchunk - 1) / (8LL * rchunk) * rchunk;
   dim3 g((unsigned)(8 * per_xcd * nxb)), b(64 * NL);
-  if (c.streamed_state)
-    hipLaunchKernelGGL((k_collide_bulk<NL, false>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
-  else
-    hipLaunchKernelGGL((k_collide_bulk<NL, true>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
+  const bool ephi = collide_takes_e_from_phi(c);
+  if (c.streamed_state) {
+    if (ephi) hipLaunchKernelGGL((k_collide_bulk<NL, false, (NL > 1)>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
+    else hipLaunchKernelGGL((k_collide_bulk<NL, false, false>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
+  } else {
+    if (ephi) hipLaunchKernelGGL((k_collide_bulk<NL, true, (NL > 1)>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
+    else hipLaunchKernelGGL((k_collide_bulk<NL, true, false>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);
+  }
   note_launch(c, "k_collide_bulk");
 }
 
@@ -651,10 +708,14 @@ static void all_dispatch(Ctx& c, const KArgs& a) {
   const int nxb = (c.p.nx + 63) / 64, rchunk = 64;
   const long long per_xcd = ((long long)nrows + 8LL * rchunk - 1) / (8LL * rchunk) * rchunk;
   dim3 g((unsigned)(8 * per_xcd * nxb)), b(64 * NL);
-  if (c.streamed_state)
-    hipLaunchKernelGGL((k_collide_all<NL, false>), g, b, 0, c.stream, a, 1, nrows_bulk, nxb, rchunk);
-  else
-    hipLaunchKernelGGL((k_collide_all<NL, true>), g, b, 0, c.stream, a, 1, nrows_bulk, nxb, rchunk);
+  const bool ephi = collide_takes_e_from_phi(c);
+  if (c.streamed_state) {
+    if (ephi) hipLaunchKernelGGL((k_collide_all<NL, false, (NL > 1)>), g, b, 0, c.stream, a, 1, nrows_bulk, nxb, rchunk);
+    else hipLaunchKernelGGL((k_collide_all<NL, false, false>), g, b, 0, c.stream, a, 1, nrows_bulk, nxb, rchunk);
+  } else {
+    if (ephi) hipLaunchKernelGGL((k_collide_all<NL, true, (NL > 1)>), g, b, 0, c.stream, a, 1, nrows_bulk, nxb, rchunk);
+    else hipLaunchKernelGGL((k_collide_all<NL, true, false>), g, b, 0, c.stream, a, 1, nrows_bulk, nxb, rchunk);
+  }
   note_launch(c, "k_collide_all");
 }
 
@@ -681,10 +742,14 @@ void launch_collide_bulk(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
 template <int NL>
 static void wall_dispatch(Ctx& c, const KArgs& a, int first_wall, int nwalls, hipStream_t stream) {
   dim3 g((unsigned)((c.p.nx + 63) / 64), (unsigned)c.p.ny, (unsigned)nwalls), b(64);
-  if (c.streamed_state)
-    hipLaunchKernelGGL((k_collide_wall<NL, false>), g, b, 0, stream, a, first_wall);
-  else
-    hipLaunchKernelGGL((k_collide_wall<NL, true>), g, b, 0, stream, a, first_wall);
+  const bool ephi = collide_takes_e_from_phi(c);
+  if (c.streamed_state) {
+    if (ephi) hipLaunchKernelGGL((k_collide_wall<NL, false, (NL > 1)>), g, b, 0, stream, a, first_wall);
+    else hipLaunchKernelGGL((k_collide_wall<NL, false, false>), g, b, 0, stream, a, first_wall);
+  } else {
+    if (ephi) hipLaunchKernelGGL((k_collide_wall<NL, true, (NL > 1)>), g, b, 0, stream, a, first_wall);
+    else hipLaunchKernelGGL((k_collide_wall<NL, true, false>), g, b, 0, stream, a, first_wall);
+  }
   note_launch(c, "k_collide_wall");
 }
 

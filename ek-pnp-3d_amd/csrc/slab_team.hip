@@ -1046,6 +1046,7 @@ extern "C" int ekpnp_group_read_state(ekpnp_group* g, const char* path, double* 
         if (ok) e = hipMemcpy(c.fld[id] + o, buf.data(), n * sizeof(double), hipMemcpyHostToDevice);
       }
       c.rhs_ready = false;
+      c.e_phi_valid = false;  // phi and E are what the file said (team_synchronize above brought the arrays up to date first)
       c.t = h.time;
     }
   std::fclose(f);

@@ -195,6 +195,15 @@ def default_params(nx: int, ny: int, nz: int) -> Params:
     return p
 
 
+def slab_extent(nz: int, rank: int, nranks: int):
+    """(first plane, number of planes) owned by `rank`: planes [rank*nz//nranks, (rank+1)*nz//nranks),
+    the same rule as ekpnp_create_slab (slabs differ by at most one plane)."""
+    if nranks > 1 and nz // nranks < 4:
+        raise ValueError("each z slab needs at least 4 planes")
+    z0 = rank * nz // nranks
+    return z0, (rank + 1) * nz // nranks - z0
+
+
 def compute_parameters(p: Params) -> dict:
     """compute_parameters (LBM.cu:2419-2446): the dimensionless groups T, M, C, Fe, Pr."""
     v = [C.c_double() for _ in range(5)]

@@ -1,46 +1,35 @@
-"""z-slab decomposition of the EK-PNP step over the GPUs of one node with the
-transport in PYTHON (torch.distributed).  Since round 2 the library moves the halos itself
-(csrc/slab_team.hip: ekpnp_slab_attach_comm / ekpnp_group_*, RCCL or peer copies on a comm stream);
-this module stays as the worked example of INTEGRATION.md section 5(c) - a host's own transport over
-the split entry points -, as the gloo rehearsal of the multi-process flow on a one-GPU box, and as
-bench.py's safety net when the in-library communicator cannot be made.
+"""A HOST'S OWN TRANSPORT over the split entry points of libekpnp.so - the worked example of INTEGRATION.md section 5(c).
 
-No reference counterpart: the reference is single-GPU (`cudaSetDevice(0)`, main.cu:58).  One
-process per GPU; rank r owns planes [r*NZ/P, (r+1)*NZ/P).  x and y stay whole, so the x-y
-periodicity and the 2-D FFTs are rank-local.  Per step a rank exchanges
+NOT part of the product package.  The library moves the halos of a z-slab run itself (csrc/slab_team.hip:
+ekpnp_slab_attach_comm / ekpnp_group_*, RCCL or peer copies on a comm stream); that is the only data path the
+package `ek-pnp-3d_amd/` has and the only one bench.py's headline lines run on.  This module shows how a host that
+already owns a communication layer (here: torch.distributed) would drive the same slab contexts through
+ekpnp_collide_boundary_planes / ekpnp_halo_pack / ... / ekpnp_poisson_stage1..3 and move the buffers itself.  It is
+used by tests (gloo rehearsal of the multi-process flow on CPU / a one-GPU box: tests/_slab_worker.py,
+tests/_ring_worker.py; `LocalSlabGroup`: every slab kernel in one process) and by bench.py only behind explicit flags
+(`--backend gloo` rehearsals, `--allow-fallback-transport`).
 
-  * LBM halo: the 9 c_z=+1 populations of its top plane go up, the 9 c_z=-1 of its bottom plane
-    go down, per active lattice (9*L*8*NX*NY bytes per face).  `gpu_stream` wraps z
-    (LBM.cu:1972,1975), so the neighbour graph is a RING (rank P-1's top plane feeds rank 0's
-    ghost plane: the wall-to-wall ghost loop of the reference).
-  * Poisson: 2 interface coefficients per (kx,ky) mode, all-gathered (4*(NX/2+1)*NY doubles per
-    rank), then every rank solves the same tiny interface system and corrects its own rows.
+No reference counterpart: the reference is single-GPU (`cudaSetDevice(0)`, main.cu:58).  One process per GPU; rank r
+owns planes [r*NZ/P, (r+1)*NZ/P).  Per step a rank exchanges
+
+  * LBM halo: the 9 c_z=+1 populations of its top plane go up, the 9 c_z=-1 of its bottom plane go down, per active
+    lattice (9*L*8*NX*NY bytes per face).  `gpu_stream` wraps z (LBM.cu:1972,1975), so the neighbour graph is a RING.
+  * Poisson: 4 interface coefficients per (kx,ky) mode, all-gathered, then every rank solves the same tiny interface
+    system and corrects its own rows.
   * one phi plane each way for Ez (poisson.cu:50-55).
 
-The exchange of the LBM halo overlaps the collision of the interior planes: boundary planes are
-collided first, packed, the exchange is started (RCCL runs it on its own stream), the interior
-is collided meanwhile, and only then the ghost planes are unpacked.
+`RingTransport` is the only place that talks to `torch.distributed`; it works on any 1-D float64 tensors (CUDA tensors
+over RCCL/"nccl", or CPU tensors over "gloo", staging through the host).  `LocalSlabGroup` runs P slab contexts inside
+ONE process on ONE device with device-to-device copies as transport.
 
-`RingTransport` is the only place that talks to `torch.distributed`; it works on any 1-D
-float64 tensors (CUDA tensors over RCCL/"nccl", or CPU tensors over "gloo" - the CPU tests and
-the two-process single-GPU test use that, staging through the host).  `LocalSlabGroup` runs P
-slab contexts inside ONE process on ONE device with device-to-device copies as transport: it
-exercises every slab kernel without a second GPU.
+Import after the package has been loaded (`__graft_entry__.load_package()`), with the repository root on sys.path:
+`from examples.host_transport import DistributedSlab`.
 """
 from __future__ import annotations
 
 import numpy as np
 
-from .solver import FIELDS, Params, Solver
-
-
-def slab_extent(nz: int, rank: int, nranks: int):
-    """(first plane, number of planes) owned by `rank`: planes [rank*nz//nranks, (rank+1)*nz//nranks),
-    the same rule as ekpnp_create_slab (slabs differ by at most one plane)."""
-    if nranks > 1 and nz // nranks < 4:
-        raise ValueError("each z slab needs at least 4 planes")
-    z0 = rank * nz // nranks
-    return z0, (rank + 1) * nz // nranks - z0
+from ek_pnp_3d_amd import FIELDS, Params, Solver, slab_extent  # noqa: F401  (the package: __graft_entry__.load_package())
 
 
 class _DevArray:

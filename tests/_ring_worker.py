@@ -1,5 +1,5 @@
 """Worker of tests/test_slab_cpu.py: run under torch.distributed.run with the gloo backend.
-Exercises the product's RingTransport (the only code that talks to torch.distributed) on CPU
+Exercises examples/host_transport.py's RingTransport (the host-side transport example) on CPU
 tensors: ring semantics (send_up -> upper neighbour's recv_lo, send_dn -> lower neighbour's
 recv_hi, wrap-around) and the rank-major all-gather."""
 import os
@@ -17,7 +17,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     G.load_package()
-    from ek_pnp_3d_amd.slab import RingTransport, slab_extent
+    from examples.host_transport import RingTransport, slab_extent
 
     tr = RingTransport(dist, rank, world)
     assert tr.host_staged

@@ -27,7 +27,7 @@ def main():
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg = G.load_package()
-    from ek_pnp_3d_amd.slab import DistributedSlab
+    from examples.host_transport import DistributedSlab  # the host-side transport example (not product code)
 
     out = os.environ["EKPNP_SLAB_OUT"]
     nx, ny, nz = (int(v) for v in os.environ["EKPNP_SLAB_GRID"].split("x"))

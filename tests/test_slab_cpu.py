@@ -28,7 +28,7 @@ def test_ring_transport_gloo(world, tmp_path):
 
 
 def test_slab_extent_rules(pkg):
-    from ek_pnp_3d_amd.slab import slab_extent
+    from ek_pnp_3d_amd import slab_extent
 
     assert slab_extent(512, 0, 1) == (0, 512)
     assert [slab_extent(1024, r, 8) for r in (0, 3, 7)] == [(0, 128), (384, 128), (896, 128)]

@@ -28,7 +28,7 @@ def _single(pkg, O, p, start, steps):
 @pytest.mark.parametrize("shape,nslabs", [((16, 12, 16), 2), ((20, 6, 24), 3), ((70, 5, 32), 4), ((16, 8, 64), 8), ((12, 6, 40), 2), ((10, 4, 16), 4), ((8, 4, 102), 3),
                                           ((18, 6, 21), 1)])
 def test_local_slab_group_equals_single_context(pkg, O, shape, nslabs):
-    from ek_pnp_3d_amd.slab import LocalSlabGroup
+    from examples.host_transport import LocalSlabGroup
 
     p = pkg.default_params(*shape)
     p.pb_iterations = 15
@@ -55,7 +55,7 @@ def test_local_slab_group_equals_single_context(pkg, O, shape, nslabs):
 def test_in_place_slabs_equal_single_context(pkg, O, shape, nslabs):
     """in_place = 1 on slab contexts: the first/last plane of a slab are collided into a staging
     buffer (they feed the halo exchange before the ordered sweep of the planes in between)."""
-    from ek_pnp_3d_amd.slab import LocalSlabGroup
+    from examples.host_transport import LocalSlabGroup
 
     p = pkg.default_params(*shape)
     p.pb_iterations = 10
@@ -80,7 +80,7 @@ def test_in_place_slabs_equal_single_context(pkg, O, shape, nslabs):
 
 
 def test_slabs_three_lattices(pkg, O):
-    from ek_pnp_3d_amd.slab import LocalSlabGroup
+    from examples.host_transport import LocalSlabGroup
 
     shape = (24, 6, 20)
     p = pkg.default_params(*shape)

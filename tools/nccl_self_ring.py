@@ -13,7 +13,7 @@ import __graft_entry__ as G
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 pkg = G.load_package()
-from ek_pnp_3d_amd.slab import RingTransport, device_tensor
+from examples.host_transport import RingTransport, device_tensor
 
 p = pkg.default_params(64, 64, 16)
 with pkg.Solver(p) as s:

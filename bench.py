@@ -418,6 +418,32 @@ def product_pb_state(sol, p, prof):
         sol.set_field(k, zero)
 
 
+def transport_or_exit(pkg, torch, dist, rank, want_native, allow_fallback):
+    """The headline N>1 line runs on the library's own RCCL transport or not at all (fail closed).  EVERY rank asks the library
+    whether it can bind RCCL (ekpnp_rccl_available: no device, no communicator), the ranks agree over the control plane, and if
+    one cannot, all of them leave together with a non-zero exit and the library's message - before a context exists and before
+    anybody is inside ncclCommInitRank.  Returns True when the native transport is to be used, False only under the explicit
+    --allow-fallback-transport (the torch.distributed example transport runs, and the line is labelled)."""
+    if not want_native:
+        return False
+    why = pkg.rccl_available()
+    bad = bool(why)
+    if dist is not None:
+        flag = torch.tensor([1 if bad else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        bad = bool(int(flag.item()))
+    if not bad:
+        return True
+    if allow_fallback and dist is not None:
+        print(f"rank {rank}: the library's RCCL transport is unavailable ({why or 'on another rank'}); --allow-fallback-transport: "
+              "the torch.distributed example transport runs instead", file=sys.stderr)
+        return False
+    if dist is not None:
+        dist.destroy_process_group()
+    raise SystemExit(f"bench.py: rank {rank}: the library's RCCL transport cannot be set up: {why or 'RCCL is unavailable on another rank'} "
+                     "(--allow-fallback-transport would run the torch.distributed example transport instead, labelled as such)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -429,8 +455,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-place", action="store_true", help="one population buffer per lattice (ekpnp_params.in_place): 0.57x the memory of cfg3")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="N>1 data path.  nccl: the library's own RCCL transport (ekpnp_slab_attach_comm).  gloo: the host-staged "
-                         "python transport of slab.py, only to rehearse the multi-rank flow on a one-GPU box")
+                    help="N>1 data path.  nccl: the library's own RCCL transport (ekpnp_slab_attach_comm) - the only one a headline line "
+                         "runs on.  gloo: the host-staged python transport of examples/host_transport.py, only to rehearse the multi-rank "
+                         "flow on a one-GPU box; the line says so")
+    ap.add_argument("--allow-fallback-transport", action="store_true",
+                    help="opt-in safety net: if the library's RCCL communicator cannot be made, move the halos with the torch.distributed "
+                         "example transport (examples/host_transport.py) and label the line FALLBACK TRANSPORT.  Without this flag such a "
+                         "failure ends every rank with a non-zero exit and the library's message")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU box: put every rank on device 0.  With --backend nccl each rank tells RCCL it is a "
                          "different host (NCCL_HOSTID), so the library's real communicator, ring and all-gather run between the "
@@ -467,11 +498,24 @@ def main():
 
         dist.init_process_group("gloo")
     if args.dry_run:
+        # every rank selects (and may reject) the workload BEFORE the first barrier: a bad grid ends all ranks with the same
+        # message instead of leaving the others waiting for rank 0
+        try:
+            sel = select_workload(args.workload, world, 300 * 10**9, args.in_place, args.weak, args.scale_z)
+        except ValueError as e:
+            if dist is not None:
+                dist.destroy_process_group()
+            raise SystemExit(f"bench.py: {e}")
+        # the transport decision of the real run, which needs no GPU either: all ranks leave non-zero if one cannot bind RCCL
+        native_dry = transport_or_exit(G.load_package(), torch, dist, rank, (world > 1 or args.force_slab) and args.backend == "nccl",
+                                       args.allow_fallback_transport)
         if dist is not None:
             dist.barrier()
         if rank == 0:
-            sel = select_workload(args.workload, world, 300 * 10**9, args.in_place, args.weak, args.scale_z)
             print(json.dumps({"metric": "MLUPS (full EK-PNP step)", "value": None, "unit": "MLUPS", "n_gpus": world, "dry_run": True, "scaling": sel["scaling"],
+                              "transport": ("none (one context)" if world == 1 and not args.force_slab else
+                                            "RCCL inside libekpnp.so" if native_dry else
+                                            "torch.distributed example transport (rehearsal / FALLBACK)"),
                               "config": {"workload": sel["label"], "grid": list(sel["grid"]), "lattices": sel["lattices"], "nodes_per_rank": sel["nodes_per_rank"],
                                          "planes_per_rank": sel["planes_per_rank"], "scaling_note": sel["scaling_note"]}}), flush=True)
         if dist is not None:
@@ -488,6 +532,10 @@ def main():
         os.environ["NCCL_HOSTID"] = f"ekpnp-rehearsal-rank{rank}"
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    if args.single_device and world > 1:
+        # ranks sharing one device must not race for its free memory: the placement search of ekpnp_create holds up to two
+        # extra population arenas for a moment, and a rank that loses that race would leave its peers in ncclCommInitRank
+        os.environ.setdefault("EKPNP_PLACEMENT_TRIES", "1")
     torch.cuda.set_device(local_rank)
     pkg = G.load_package()
 
@@ -504,7 +552,10 @@ def main():
         raise SystemExit(f"bench.py: {e}")
     wname, (nx, ny, nz_global), nl, use_in_place = sel["name"], sel["grid"], sel["lattices"], sel["in_place"]
     slab_path = world > 1 or args.force_slab
-    native = slab_path and args.backend == "nccl"
+    fell_back = False  # True: --allow-fallback-transport and the library's own RCCL transport could not be set up: the example transport moved the halos
+    native = transport_or_exit(pkg, torch, dist, rank, slab_path and args.backend == "nccl", args.allow_fallback_transport)
+    if slab_path and args.backend == "nccl" and not native:
+        fell_back = True
     saved_stdout = None
     if slab_path:
         # RCCL prints a version banner on the C-level stdout when its first communicator is made;
@@ -541,7 +592,6 @@ def main():
         prof, ic_note = pb_profile_from_product(pkg, p)  # before the big allocation, on this rank's own GPU
 
     err, runner, sol = None, None, None
-    fell_back = False  # True: the library's own RCCL transport could not be set up and slab.py's moved the halos instead
     try:
         if not slab_path:
             sol = runner = pkg.Solver(p)
@@ -552,7 +602,7 @@ def main():
             if rehearsal:
                 transport += " - REHEARSAL: all ranks share device 0, RCCL socket transport; not a bandwidth figure"
         else:
-            from ek_pnp_3d_amd.slab import DistributedSlab  # noqa: WPS433
+            from examples.host_transport import DistributedSlab  # noqa: WPS433  (--backend gloo: the rehearsal transport, not product code)
 
             if dist is None:  # --force-slab --backend gloo
                 import socket
@@ -563,9 +613,13 @@ def main():
                     sk.bind(("127.0.0.1", 0))
                     port = sk.getsockname()[1]
                 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-            runner = DistributedSlab(p, rank, world, dist)
+            if fell_back:  # --allow-fallback-transport and RCCL cannot be bound by the library: torch's own RCCL process group moves the halos
+                runner = DistributedSlab(p, rank, world, dist, group=dist.new_group(backend="nccl"))
+                transport = "torch.distributed RCCL process group (fallback: the library cannot bind RCCL)"
+            else:
+                runner = DistributedSlab(p, rank, world, dist)
+                transport = "torch.distributed gloo, host-staged (rehearsal)"
             sol = runner.solver
-            transport = "torch.distributed gloo, host-staged (rehearsal)"
     except Exception as e:  # noqa: BLE001
         err = e
     agree(err)
@@ -588,14 +642,19 @@ def main():
             flag = torch.tensor([1 if failed else 0], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             failed = bool(int(flag.item()))
-        if failed and dist is None:
-            raise SystemExit(f"bench.py: the library's RCCL transport could not be set up: {err}")
+        if failed and (dist is None or not args.allow_fallback_transport):
+            # FAIL CLOSED: a headline line is only ever measured on the library's own transport.  Every rank learnt of the
+            # failure through the all_reduce above and leaves here together, non-zero, with the library's message.
+            if dist is not None:
+                dist.destroy_process_group()
+            raise SystemExit(f"bench.py: rank {rank}: the library's RCCL transport could not be set up"
+                             f"{' on at least one rank' if err is None else ''}: {err if err is not None else 'see the other ranks'} "
+                             "(--allow-fallback-transport would run the torch.distributed example transport instead, labelled as such)")
         if failed:
-            # Safety net for a node where the in-library communicator cannot be made: the same slab
-            # contexts, halos moved by torch.distributed's own RCCL process group (slab.py) - the
-            # JSON line says which transport ran.  Every rank takes this branch together.
-            print(f"rank {rank}: ekpnp_slab_attach_comm failed ({err}); falling back to the torch.distributed RCCL transport", file=sys.stderr)
-            from ek_pnp_3d_amd.slab import DistributedSlab  # noqa: WPS433
+            # --allow-fallback-transport: the same slab contexts, halos moved by torch.distributed's own RCCL process
+            # group (examples/host_transport.py) - the JSON line says which transport ran.  Every rank takes this branch together.
+            print(f"rank {rank}: ekpnp_slab_attach_comm failed ({err}); --allow-fallback-transport: the torch.distributed RCCL example transport runs instead", file=sys.stderr)
+            from examples.host_transport import DistributedSlab  # noqa: WPS433
 
             sol.close()
             data_group = dist.new_group(backend="nccl")
@@ -736,7 +795,7 @@ def main():
             # a line measured on the python safety-net transport must not pass for the library's: said at the top level
             out["transport_fallback"] = fell_back
             # the scaling loss, itemised: what the compute stream waited for, what the exchanges took, what they moved
-            out["comm"] = comm if comm is not None else {"source": "not measured: the python transport (slab.py) ran, not the library's"}
+            out["comm"] = comm if comm is not None else {"source": "not measured: the python example transport (examples/host_transport.py) ran, not the library's"}
         if world == 1 and not args.no_cpu_baseline:
             runner.close()
             out["cpu_baseline"] = cpu_baseline_in_child(nl)

@@ -23,5 +23,6 @@ from .solver import (  # noqa: F401
     exported_symbols,
     library_path,
     load_library,
+    rccl_available,
     slab_extent,
 )

@@ -53,10 +53,27 @@ namespace ekpnp {
 void set_create_error(const std::string& msg) { g_create_err = msg; }
 void note_launch(Ctx& c, const char* kernel) {
   static const bool debug_sync = std::getenv("EKPNP_DEBUG_SYNC") != nullptr;
-  // fault injection for the tests of this very path: EKPNP_INJECT_LAUNCH_FAILURE=<kernel name>
-  static const char* const inject = std::getenv("EKPNP_INJECT_LAUNCH_FAILURE");
+  // fault injection for the tests of this very path: EKPNP_INJECT_LAUNCH_FAILURE=<kernel name>[@<slab rank>][#<n>]
+  // (only on the context of that rank; only the n-th launch of that kernel on a context, counted from 1)
+  struct Inject { std::string name; int rank = -1; long nth = 0; bool on = false; };
+  static const Inject inject = [] {
+    Inject j;
+    if (const char* v = std::getenv("EKPNP_INJECT_LAUNCH_FAILURE")) {
+      std::string t = v;
+      const size_t h = t.rfind('#');
+      if (h != std::string::npos) { j.nth = std::atol(t.c_str() + h + 1); t.erase(h); }
+      const size_t r = t.rfind('@');
+      if (r != std::string::npos) { j.rank = std::atoi(t.c_str() + r + 1); t.erase(r); }
+      j.name = t;
+      j.on = !t.empty();
+    }
+    return j;
+  }();
   hipError_t e = hipGetLastError();
-  if (inject && e == hipSuccess && std::strcmp(inject, kernel) == 0) e = hipErrorLaunchFailure;
+  if (inject.on && e == hipSuccess && inject.name == kernel && (inject.rank < 0 || inject.rank == c.rank)) {
+    ++c.inject_seen;
+    if (inject.nth <= 0 || c.inject_seen == inject.nth) e = hipErrorLaunchFailure;
+  }
   if (e == hipSuccess && debug_sync) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c.stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) e = hipStreamSynchronize(c.stream);

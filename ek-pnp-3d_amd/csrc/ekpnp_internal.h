@@ -249,6 +249,7 @@ struct Ctx {
   // first kernel launch that failed since the last check (note_launch / take_launch_error)
   hipError_t launch_err = hipSuccess;
   const char* launch_what = nullptr;
+  long inject_seen = 0;  // launches of the kernel EKPNP_INJECT_LAUNCH_FAILURE names, on this context (tests)
   // kernel timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;

@@ -39,6 +39,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional: only used to tear down after a failed collective
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -74,6 +75,7 @@ static Rccl* rccl(std::string& err) {
       bind(r.CommInitRank, "ncclCommInitRank");
       bind(r.CommInitAll, "ncclCommInitAll");
       bind(r.CommDestroy, "ncclCommDestroy");
+      r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.handle, "ncclCommAbort"));
       bind(r.GroupStart, "ncclGroupStart");
       bind(r.GroupEnd, "ncclGroupEnd");
       bind(r.Send, "ncclSend");
@@ -112,6 +114,11 @@ struct Team {
   std::vector<size_t> xev_used[X_KINDS];
   double t = 0.0;
   std::string err;
+  // in-process groups (ekpnp_group_*): a verb that failed on one slab has left the others one call behind or ahead -
+  // the group is drained, marked, and answers every further verb with the first failure (group_fail)
+  bool poisoned = false;
+  std::string poison;
+  bool comm_broken = false;  // an RCCL call failed inside a collective: its kernels may never finish, the communicators are aborted, not drained
 };
 
 static inline Ctx& S(Team& T, int i) { return T.m[i]->c; }
@@ -238,11 +245,19 @@ static int exchange_begin(Team& T, int x) {
       }
       if (r != ncclSuccess) {
         (void)T.nc->GroupEnd();
+        T.comm_broken = true;  // some ranks' operations may have been issued without their partners'
         T.err = std::string("RCCL exchange failed: ") + T.nc->GetErrorString(r);
         return EKPNP_ERR_HIP;
       }
     }
-    TNCCL(T, T.nc->GroupEnd());
+    {
+      const ncclResult_t ge = T.nc->GroupEnd();
+      if (ge != ncclSuccess) {
+        T.comm_broken = true;
+        T.err = std::string("ncclGroupEnd: ") + T.nc->GetErrorString(ge);
+        return EKPNP_ERR_HIP;
+      }
+    }
   } else {
     for (int i = 0; i < n; ++i) {
       Ctx& c = S(T, i);
@@ -549,6 +564,13 @@ static int team_make_streams(Team& T) {
 }
 
 static void team_release(Team& T) {
+  if (T.comm_broken && T.nc && T.nc->CommAbort) {
+    // a collective failed half-issued: its kernels wait for partners that never come - abort them first (untested on
+    // hardware: no RCCL failure could be provoked on the one-GPU boxes; the ordinary path below is what the tests run)
+    for (size_t i = 0; i < T.comm.size(); ++i)
+      if (T.comm[i]) (void)T.nc->CommAbort(T.comm[i]);
+    T.comm.clear();
+  }
   for (size_t i = 0; i < T.m.size(); ++i) {
     (void)hipSetDevice(S(T, (int)i).device);
     if (i < T.cs.size() && T.cs[i]) (void)hipStreamSynchronize(T.cs[i]);
@@ -695,6 +717,13 @@ extern "C" int ekpnp_comm_unique_id(void* id128) {
   static_assert(sizeof(id) == EKPNP_UNIQUE_ID_BYTES, "ncclUniqueId size");
   std::memcpy(id128, &id, sizeof id);
   return EKPNP_OK;
+}
+
+extern "C" int ekpnp_rccl_available(void) {
+  std::string err;
+  if (rccl(err)) return EKPNP_OK;
+  set_create_error("ekpnp_rccl_available: " + err);
+  return EKPNP_ERR_HIP;
 }
 
 extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
@@ -846,6 +875,42 @@ extern "C" int ekpnp_group_create(const ekpnp_params* p, int nslabs, const int* 
   if (!(g)) return EKPNP_ERR_INVALID;   \
   DeviceGuard device_guard_;            \
   Team& T = (g)->t
+// ... and the group has not been poisoned by an earlier failure (every verb that computes, exchanges or reads device state)
+#define NEEDLIVEGROUP(g)                                                                              \
+  NEEDGROUP(g);                                                                                       \
+  if (T.poisoned) {                                                                                   \
+    T.err = "this group is poisoned (destroy it; ekpnp_group_last_error keeps the cause): " + T.poison; \
+    return EKPNP_ERR_INVALID;                                                                         \
+  }
+
+// Failure of a group verb.  In an in-process group every slab is driven by this one host thread, so
+// a non-OK status from one slab is fully local: nobody is waiting inside a collective for a peer process.  But the other
+// slabs have work enqueued that the failed slab's part never joined (one has collided, the next has not; an exchange was
+// begun or not).  The call therefore returns only after EVERY slab's compute and comm stream has drained (no kernel of
+// the group is running when the caller sees the error), the slabs' per-step state is reset, and the group is POISONED:
+// its fields are from mixed steps, so every further verb answers EKPNP_ERR_INVALID with the first failure, and only
+// ekpnp_group_destroy / _last_error / _size / _transport / _context remain.  Attached ranks (one process per GPU) keep
+// the documented contract: the control plane ends all ranks.
+static int group_fail(Team& T, int rc) {
+  if (rc == EKPNP_OK || !T.group) return rc;
+  const std::string first = T.err;
+  for (size_t i = 0; i < T.m.size(); ++i) {
+    Ctx& c = S(T, (int)i);
+    if (hipSetDevice(c.device) != hipSuccess) continue;
+    if (!T.comm_broken && i < T.cs.size() && T.cs[i]) (void)hipStreamSynchronize(T.cs[i]);
+    if (!T.comm_broken && c.stream) (void)hipStreamSynchronize(c.stream);
+    (void)hipGetLastError();
+    c.launch_err = hipSuccess;
+    c.launch_what = nullptr;
+    c.collide_phase = 0;
+  }
+  if (!T.poisoned) {
+    T.poisoned = true;
+    T.poison = first;
+  }
+  T.err = first;
+  return rc;
+}
 
 extern "C" int ekpnp_group_size(const ekpnp_group* g) { return g ? (int)g->t.m.size() : 0; }
 extern "C" int ekpnp_group_transport(const ekpnp_group* g) { return g ? g->t.kind : 0; }
@@ -863,14 +928,13 @@ extern "C" size_t ekpnp_group_device_bytes(const ekpnp_group* g) {
   return b;
 }
 
-extern "C" int ekpnp_group_synchronize(ekpnp_group* g) { NEEDGROUP(g); return team_synchronize(T); }
-extern "C" int ekpnp_group_initialization(ekpnp_group* g) { NEEDGROUP(g); return team_initialization(T); }
+extern "C" int ekpnp_group_synchronize(ekpnp_group* g) { NEEDLIVEGROUP(g); return group_fail(T, team_synchronize(T)); }
+extern "C" int ekpnp_group_initialization(ekpnp_group* g) { NEEDLIVEGROUP(g); return group_fail(T, team_initialization(T)); }
 extern "C" int ekpnp_group_initialization_converged(ekpnp_group* g, double rel_tol, int max_sweeps, int* sweeps, double* residual) {
-  NEEDGROUP(g);
-  return team_initialization_converged(T, rel_tol, max_sweeps, sweeps, residual);
+  NEEDLIVEGROUP(g);
+  return group_fail(T, team_initialization_converged(T, rel_tol, max_sweeps, sweeps, residual));
 }
-extern "C" int ekpnp_group_init_equilibrium(ekpnp_group* g) {
-  NEEDGROUP(g);
+static int team_init_equilibrium(Team& T) {
   for (size_t i = 0; i < T.m.size(); ++i) {
     int rc = use(T, (int)i);
     if (rc) return rc;
@@ -878,9 +942,10 @@ extern "C" int ekpnp_group_init_equilibrium(ekpnp_group* g) {
   }
   return EKPNP_OK;
 }
-extern "C" int ekpnp_group_stream_collide_save(ekpnp_group* g, double t) { NEEDGROUP(g); (void)t; return team_stream_collide_save(T); }
-extern "C" int ekpnp_group_fast_poisson(ekpnp_group* g) { NEEDGROUP(g); return team_fast_poisson(T); }
-extern "C" int ekpnp_group_step(ekpnp_group* g, int nsteps) { NEEDGROUP(g); return team_step(T, nsteps); }
+extern "C" int ekpnp_group_init_equilibrium(ekpnp_group* g) { NEEDLIVEGROUP(g); return group_fail(T, team_init_equilibrium(T)); }
+extern "C" int ekpnp_group_stream_collide_save(ekpnp_group* g, double t) { NEEDLIVEGROUP(g); (void)t; return group_fail(T, team_stream_collide_save(T)); }
+extern "C" int ekpnp_group_fast_poisson(ekpnp_group* g) { NEEDLIVEGROUP(g); return group_fail(T, team_fast_poisson(T)); }
+extern "C" int ekpnp_group_step(ekpnp_group* g, int nsteps) { NEEDLIVEGROUP(g); return group_fail(T, team_step(T, nsteps)); }
 
 extern "C" int ekpnp_group_get_time(ekpnp_group* g, double* t) {
   NEEDGROUP(g);
@@ -895,7 +960,7 @@ extern "C" int ekpnp_group_set_time(ekpnp_group* g, double t) {
 
 // whole-lattice host arrays [NZ][NY][NX] <-> the slabs' planes
 extern "C" int ekpnp_group_set_field(ekpnp_group* g, int field_id, const double* host) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!host) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
   for (size_t i = 0; i < T.m.size(); ++i) {
     int rc = use(T, (int)i);
@@ -905,7 +970,7 @@ extern "C" int ekpnp_group_set_field(ekpnp_group* g, int field_id, const double*
   return EKPNP_OK;
 }
 extern "C" int ekpnp_group_get_field(ekpnp_group* g, int field_id, double* host) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!host) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
   for (size_t i = 0; i < T.m.size(); ++i) {
     int rc = use(T, (int)i);
@@ -928,17 +993,17 @@ static int group_diag(Team& T, bool is_max, double* out) {
   return team_reduce(T, v, is_max, out);
 }
 extern "C" int ekpnp_group_current(ekpnp_group* g, double* I) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!I) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
   return group_diag(T, false, I);
 }
 extern "C" int ekpnp_group_umax(ekpnp_group* g, double* umax) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!umax) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
   return group_diag(T, true, umax);
 }
 extern "C" int ekpnp_group_record_umax(ekpnp_group* g, const char* path, int append, double time) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
   double um = 0.0;
   int rc = group_diag(T, true, &um);
@@ -957,13 +1022,13 @@ static int write_part(Ctx& c, void* arg) {
   return io_write_text_part(c, a);
 }
 extern "C" int ekpnp_group_save_data_tecplot(ekpnp_group* g, const char* path, int append, double time, int first) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
   TextIoArgs a{path, append, time, first, 0};
   return team_turns(T, write_part, &a);
 }
 extern "C" int ekpnp_group_save_data_end(ekpnp_group* g, const char* path, int append, double time) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
   TextIoArgs a{path, append, time, 0, 1};
   return team_turns(T, write_part, &a);
@@ -976,7 +1041,7 @@ int read_part(Ctx& c, void* arg) {
 }
 }  // namespace
 extern "C" int ekpnp_group_read_data(ekpnp_group* g, const char* path, double* time) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!path || !time) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
   ReadArgs a{path, time};
   return team_turns(T, read_part, &a);
@@ -984,7 +1049,7 @@ extern "C" int ekpnp_group_read_data(ekpnp_group* g, const char* path, double* t
 
 // whole-lattice EKPNPST1 file (same format a single context writes: z0 = 0, nz_local = nz)
 extern "C" int ekpnp_group_save_state(ekpnp_group* g, const char* path, double time) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
   int rc = team_synchronize(T);
   if (rc) return rc;
@@ -1015,7 +1080,7 @@ extern "C" int ekpnp_group_save_state(ekpnp_group* g, const char* path, double t
 }
 
 extern "C" int ekpnp_group_read_state(ekpnp_group* g, const char* path, double* time) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!path || !time) { T.err = "NULL pointer"; return EKPNP_ERR_INVALID; }
   int rc = team_synchronize(T);
   if (rc) return rc;
@@ -1059,7 +1124,7 @@ extern "C" int ekpnp_group_read_state(ekpnp_group* g, const char* path, double* 
 // whole-lattice EKPNPCK1 checkpoint (fields + post-collision populations): the file a single
 // context writes with ekpnp_save_checkpoint; loading continues the run bit for bit
 extern "C" int ekpnp_group_save_checkpoint(ekpnp_group* g, const char* path) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
   int rc = team_synchronize(T);
   if (rc) return rc;
@@ -1079,7 +1144,7 @@ extern "C" int ekpnp_group_save_checkpoint(ekpnp_group* g, const char* path) {
 }
 
 extern "C" int ekpnp_group_load_checkpoint(ekpnp_group* g, const char* path, double* time) {
-  NEEDGROUP(g);
+  NEEDLIVEGROUP(g);
   if (!path) { T.err = "NULL path"; return EKPNP_ERR_INVALID; }
   int rc = team_synchronize(T);
   if (rc) return rc;

@@ -150,6 +150,7 @@ def load_library():
         "ekpnp_save_scalar": (i32, [ctx, C.c_char_p, i32, C.c_uint, C.c_uint]),
         # the library's own halo transport (RCCL / peer copies)
         "ekpnp_comm_unique_id": (i32, [C.c_void_p]),
+        "ekpnp_rccl_available": (i32, []),
         "ekpnp_slab_attach_comm": (i32, [ctx, C.c_void_p]),
         "ekpnp_comm_timing_get": (i32, [ctx, i32, C.POINTER(i32), pd, pd, C.POINTER(sz)]),
         "ekpnp_group_create": (i32, [C.POINTER(Params), i32, C.POINTER(i32), i32, C.POINTER(ctx)]),
@@ -224,6 +225,15 @@ def comm_unique_id() -> bytes:
     if rc:
         raise EkpnpError(f"ekpnp_comm_unique_id -> {rc} (librccl.so.1 not loadable?)")
     return buf.raw
+
+
+def rccl_available() -> str:
+    """'' when this process can bind the RCCL library the transport uses (ekpnp_rccl_available: no device, no
+    communicator), else the loader's message.  Hosts call it on every rank and agree BEFORE attaching."""
+    L = load_library()
+    if L.ekpnp_rccl_available() == 0:
+        return ""
+    return (L.ekpnp_last_error(None) or b"RCCL cannot be bound").decode()
 
 
 COMM_KINDS = ("halo", "phi", "edge")  # ekpnp_comm_timing_get kinds 0, 1, 2

@@ -313,9 +313,17 @@ int ekpnp_advance_time(ekpnp_ctx* ctx);
  * make the same calls in the same order.  ekpnp_destroy releases the communicator. */
 int ekpnp_comm_unique_id(void* id128);  /* on failure the message is in ekpnp_last_error(NULL) */
 int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128);
+/* Can this process bind the RCCL library (dlopen + every symbol the transport uses)?  EKPNP_OK, or EKPNP_ERR_HIP with
+ * the reason in ekpnp_last_error(NULL).  Needs no device and makes no communicator.  A host calls it on EVERY rank and
+ * agrees on the result over its control plane BEFORE anybody attaches: a rank that cannot bind RCCL returns from
+ * ekpnp_slab_attach_comm before the collective, and its peers would wait in theirs (bench.py does exactly this). */
+int ekpnp_rccl_available(void);
 /* Failure semantics of the collective calls (no reference counterpart: the reference exit()s on any error,
- * LBM.cu:35-53).  ekpnp_slab_attach_comm always enters ncclCommInitRank, also on a rank whose local set-up
- * failed, so its peers return.  Between the turns of the whole-lattice file IO the ranks agree on a common
+ * LBM.cu:35-53).  Once RCCL is bound and the (small, host-side) team object exists, ekpnp_slab_attach_comm always
+ * enters ncclCommInitRank, also on a rank whose stream / event set-up failed, so its peers return; the returns BEFORE
+ * that point - a NULL or non-slab context, a context that already has a transport, RCCL not bindable on this rank
+ * (ekpnp_rccl_available), host allocation failure - leave the peers waiting, and the control plane must end all
+ * ranks as below.  Between the turns of the whole-lattice file IO the ranks agree on a common
  * status (a file one rank cannot open fails the call on every rank), and the residual / NaN test of
  * ekpnp_initialization_converged is a maximum over the ranks (all stop in the same sweep).  Everywhere else a rank that returns
  * a non-OK status from a verb of an attached slab has NOT taken part in that verb's exchanges: its peers
@@ -338,7 +346,13 @@ int ekpnp_comm_timing_get(ekpnp_ctx* ctx, int kind, int* n_exchanges, double* wa
  * together by one host thread.  Devices may repeat (then the transport is COPY: RCCL refuses two
  * ranks on one device) - that is how the whole multi-slab path is tested on a one-GPU box.  The
  * calls mirror the single-context ones (same reference citations); fields cross the boundary as
- * whole-lattice host arrays [NZ][NY][NX]; files are the single-context formats byte for byte. */
+ * whole-lattice host arrays [NZ][NY][NX]; files are the single-context formats byte for byte.
+ * Failure of a group verb: every slab is driven by the calling host thread, so a non-OK status from one slab is local -
+ * nobody waits inside a collective for another process.  The call returns only after every slab's compute and comm
+ * stream has drained (no kernel of the group is running when the caller sees the error), and the group is then POISONED:
+ * some slabs have taken part in the failed verb and some have not, so every further verb that computes, exchanges or
+ * reads device state answers EKPNP_ERR_INVALID with the first failure in ekpnp_group_last_error; ekpnp_group_destroy
+ * (always clean), _last_error, _size, _transport and _context remain. */
 typedef struct ekpnp_group ekpnp_group;
 int ekpnp_group_create(const ekpnp_params* p, int nslabs, const int* devices, int transport, ekpnp_group** out);
 int ekpnp_group_destroy(ekpnp_group* g);

@@ -125,3 +125,57 @@ def test_world_size_must_match_gpus():
     env = dict(os.environ, RANK="0", WORLD_SIZE="3", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def _run_dry(args, extra_env, timeout=600):
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_headline_multi_gpu_line_fails_closed_without_the_library_transport():
+    """the N>1 line runs on the library's own RCCL transport or not at all.  With an RCCL library that
+    cannot be bound (EKPNP_RCCL_LIBRARY names a file that does not exist) every rank must leave non-zero with the library's
+    message and print NO JSON line - the decision needs no GPU, so --dry-run takes the same code path
+    (bench.transport_or_exit).  Only the explicit --allow-fallback-transport lets the example transport stand in, and the
+    line then says so."""
+    import json
+
+    bad = {"EKPNP_RCCL_LIBRARY": "/nonexistent/librccl.so.1"}
+    r = _run_dry(["--gpus", "2", "--dry-run"], bad)
+    assert r.returncode != 0, r.stdout
+    assert "cannot be loaded" in r.stderr and "the library's RCCL transport cannot be set up" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")], r.stdout
+    # one rank through the multi-rank code path: same rule
+    r1 = _run_dry(["--force-slab", "--dry-run"], bad)
+    assert r1.returncode != 0 and "cannot be loaded" in r1.stderr
+    # opt-in: the line is printed and names the transport that would run
+    ok = _run_dry(["--gpus", "2", "--dry-run", "--allow-fallback-transport"], bad)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    out = json.loads([l for l in ok.stdout.splitlines() if l.strip()][0])
+    assert "FALLBACK" in out["transport"]
+    # and with RCCL in place the dry run names the library's transport
+    good = _run_dry(["--gpus", "2", "--dry-run"], {})
+    assert good.returncode == 0, good.stderr[-2000:]
+    assert json.loads([l for l in good.stdout.splitlines() if l.strip()][0])["transport"] == "RCCL inside libekpnp.so"
+
+
+def test_dry_run_rejects_a_bad_workload_on_every_rank():
+    """only rank 0 used to select the workload in --dry-run, and its ValueError left the other ranks in a barrier."""
+    r = _run_dry(["--gpus", "2", "--dry-run", "--workload", "16x16x6"], {}, timeout=300)
+    assert r.returncode != 0 and "bench.py:" in r.stderr and "Traceback" not in r.stderr.split("bench.py:")[0][-400:], r.stderr[-2000:]
+
+
+def test_the_package_has_no_second_data_path():
+    """The python transport is an example outside the package (examples/host_transport.py), not product code."""
+    pkg_dir = os.path.join(ROOT, "ek-pnp-3d_amd")
+    assert not os.path.exists(os.path.join(pkg_dir, "slab.py"))
+    for name in os.listdir(pkg_dir):
+        if name.endswith(".py"):
+            txt = open(os.path.join(pkg_dir, name)).read()
+            for verb in ("P2POp", "isend", "irecv", "all_gather", "all_reduce", "init_process_group", "batch_isend_irecv"):
+                assert verb not in txt, (name, verb)  # nothing in the package moves data (or anything else) through torch.distributed
+    assert os.path.exists(os.path.join(ROOT, "examples", "host_transport.py"))

@@ -267,25 +267,14 @@ def _same_profiles(a, b):
         assert np.abs(a[k] - b[k]).max() <= tol * np.abs(b[k]).max(), (k, np.abs(a[k] - b[k]).max(), np.abs(b[k]).max())
 
 
-def test_cfg4_whole_lattice_512x512x1024_in_place(pkg):
-    """cfg4's lattice (268 M nodes x 4 lattices, 276 GB in place - beyond the reference's 32-bit
-    indices) on one MI355X: an x-y uniform problem does not know NX, NY, so its z profiles must equal
-    those of a 64x64x1024 run (only the FFT sizes, i.e. rounding, differ)."""
-    import torch
+def test_cfg4_whole_lattice_512x512x1024_in_place_periodic_tiles(pkg, O):
+    """cfg4's lattice (268 M nodes x 4 lattices, 276 GB in place: population element indices beyond 2^32, where the
+    reference's 32-bit index arithmetic, LBM.cu:27-30, has long wrapped) on one MI355X, with x-y structured data: every one
+    of the 8 x 8 replicas of a perturbed 64 x 64 tile - the one holding element 2^32 of a population buffer (plane 605,
+    row 417) included - must equal the 64 x 64 x 1024 run (tests/_periodic_tiles.py)."""
+    from _periodic_tiles import periodic_tile_check
 
-    _uniform_profiles.pkg = pkg
-    free_b, _ = torch.cuda.mem_get_info()
-    if free_b < 282e9:
-        pytest.skip("needs 277 GB of free HBM")
-    prof = {}
-    for n in (64, 512):
-        p = pkg.default_params(n, n, 1024)
-        p.in_place = 1
-        with pkg.Solver(p) as s:
-            prof[n] = _uniform_profiles(s, p, 3)
-            if n == 512:
-                assert s.device_bytes() > 270e9
-    _same_profiles(prof[512], prof[64])
+    periodic_tile_check(pkg, O, 1024, 1, 3, 282e9, 32)
 
 
 def test_cfg5_per_rank_slab_1024x1024x128_through_the_transport(pkg):
@@ -519,3 +508,56 @@ def test_serial_slab_z_solve_still_matches_the_oracle(pkg, O, monkeypatch, shape
     ref = _oracle_run(O, po, 7)
     with pkg.Group(_mirror(pkg, po), nslabs, devices=[0] * nslabs) as g:
         _drive(O, g, po, ref, 7)
+
+
+def test_a_failed_group_verb_returns_drained_and_poisons_the_group(tmp_path):
+    """a per-slab failure inside an in-process group is local (one host thread drives all slabs).  The
+    library's fault-injection knob rejects ONE launch on ONE slab - the second bulk sweep of slab 1 of 3, i.e. in the
+    middle of ekpnp_group_step(4), after slab 0 has already collided and begun nothing it waits for.  The test must see:
+    the error returned from ekpnp_group_step with the kernel and the slab named; nothing of the group still running on
+    the device when the call returns (a hipDeviceSynchronize right after returns at once and cleanly); every further verb
+    refused with the FIRST failure; ekpnp_group_destroy clean; and the device fully usable afterwards in the same process
+    (a fresh group runs the same steps and matches a run that never failed) - no leaked GPU holder."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, time, ctypes, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as G
+pkg = G.load_package()
+import torch
+p = pkg.default_params(40, 6, 36); p.pb_iterations = 4
+free0 = torch.cuda.mem_get_info()[0]
+g = pkg.Group(p, 3, devices=[0, 0, 0])
+g.initialization(); g.init_equilibrium()
+try:
+    g.step(4)
+    print("NOERR")
+except pkg.EkpnpError as e:
+    print("ERR1", e)
+hip = ctypes.CDLL("libamdhip64.so")
+t0 = time.perf_counter(); rc = hip.hipDeviceSynchronize(); dt = time.perf_counter() - t0
+print("SYNC", rc, "FAST" if dt < 0.5 else "SLOW %%.2f" %% dt)
+for verb in (lambda: g.step(1), lambda: g.get_field("rho"), lambda: g.fast_Poisson(), lambda: g.synchronize()):
+    try:
+        verb(); print("NOT REFUSED")
+    except pkg.EkpnpError as e:
+        print("ERR2", e)
+g.close()
+torch.cuda.synchronize()
+free1 = torch.cuda.mem_get_info()[0]
+print("LEAK", free0 - free1 > (64 << 20))
+'''
+    body = code % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EKPNP_INJECT_LAUNCH_FAILURE="k_collide_bulk@1#4")  # slab 1: 2 bulk launches per step (boundary plane, interior) -> the interior sweep of step 2
+    r = subprocess.run([sys.executable, "-c", body], env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout
+    assert r.returncode == 0, (out, r.stderr[-3000:])
+    assert "NOERR" not in out and "ERR1" in out and "kernel k_collide_bulk" in out and "slab 1" in out, out
+    assert "SYNC 0 FAST" in out, out
+    assert out.count("ERR2") == 4 and "NOT REFUSED" not in out and out.count("poisoned") >= 4, out
+    for line in out.splitlines():
+        if line.startswith("ERR2"):
+            assert "kernel k_collide_bulk" in line, line  # the first failure, kept
+    assert "LEAK False" in out, out

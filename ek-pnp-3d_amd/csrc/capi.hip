@@ -105,6 +105,11 @@ extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
   if (std::strcmp(knob, "ab_zchunk") == 0 && value >= 0) { c.ab_zchunk = value; return EKPNP_OK; }
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
+  if (std::strcmp(knob, "tri_pipe") == 0 && (value == 0 || value == 1)) {  // the A/B partner of the pipelined z solves
+    c.tri_pipe = value != 0 && c.tri_lds_ok && tridiag_pipe_prepare_device();
+    drop_graph(c);
+    return EKPNP_OK;
+  }
   if (std::strcmp(knob, "lazy_efield") == 0 && (value == 0 || value == 1)) {  // the A/B partner of the EPHI kernels: 0 = k_phi_efield in every solve
     const int rc = ensure_efield(c);
     c.lazy_efield = value;
@@ -316,9 +321,15 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.own_stream = true;
   if (hipGetDevice(&c.device) != hipSuccess) { c.err = "hipGetDevice failed"; return bail(EKPNP_ERR_HIP); }
   c.tri_lds_ok = tridiag_prepare_device();
+  if (hipDeviceGetAttribute(&c.ncus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || c.ncus < 1) { (void)hipGetLastError(); c.ncus = 256; }
+  {
+    const char* e = std::getenv("EKPNP_TRI_PIPE");
+    c.tri_pipe = c.tri_lds_ok && (!e || std::atoi(e) != 0) && tridiag_pipe_prepare_device();
+  }
   if (const char* e = std::getenv("EKPNP_BULK_ZCHUNK")) c.ab_zchunk = std::atoi(e) > 0 ? std::atoi(e) : 0;
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
   if (const char* e = std::getenv("EKPNP_LAZY_E")) c.lazy_efield = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("EKPNP_HALO_DIRECT")) c.halo_direct = std::atoi(e) != 0;
   if (const char* e = std::getenv("EKPNP_TRI_PARTITION")) c.tri_partition = std::atoi(e) < 0 ? 0 : (std::atoi(e) > 2 ? 2 : std::atoi(e));
   // In-place mode: one buffer per lattice with `shift` spare planes.  A sweep writes plane z of
   // the new state `shift` planes below (parity 0, bulk launches of `zchunk` planes in ascending z)
@@ -819,6 +830,7 @@ extern "C" int ekpnp_initialization_converged(ekpnp_ctx* ctx, double rel_tol, in
 extern "C" int ekpnp_init_equilibrium(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (int rc = ensure_efield(c)) return rc;  // the equilibria drift with u + K E (LBM.cu:207-462): the E arrays are read
+  c.halo_recv_valid = false;  // the next step does not pull, and the halos of the old populations mean nothing to the new ones
   launch_init_equilibrium(c);
   c.streamed_state = true;
   LAUNCHCHK(c);
@@ -884,36 +896,54 @@ static void ordered_bulk(Ctx& c, int zb, int ze, int lead = 0) {
 // Where the population arena lies in HBM decides how fast the sweep runs on lattices that fill only part of the device:
 // the SAME context re-created in one process sweeps a 512x512x128 lattice in 9.65 ... 11.0 ms (identical virtual addresses,
 // physically contiguous or not: profiles/r03_placement_spread_thin_lattices.log), while a plain copy varies by 2 % and cfg3,
-// whose arena is most of the device, does not vary at all.  The sweep keeps ~300 sequential streams in flight; which of
-// them meet in the same DRAM banks depends on the physical addresses.  So when there is room, a context tries up to
-// EKPNP_PLACEMENT_TRIES (default 3; 1 = off) arenas - each allocated while the earlier ones are still held, hence
-// somewhere else - times three sweeps of the real kernel on each, keeps the fastest and frees the rest (~0.1 s once
-// per context).  The arithmetic never sees the difference.
+// whose arena is most of the device, does not vary at all.  Counters (round 4, profiles/r04_thin_slab_512x512x128_pmc_sq_lds_tcc_hbm.json):
+// the slow placements move the SAME bytes (0.47697 GB per plane, cfg3: 0.47698) at the SAME L2 hit rate (0.3743 / 0.3742) -
+// it is DRAM service time, i.e. which of the ~300 sequential streams of the sweep meet in the same banks, that differs.
+// So when there is room, a context tries up to EKPNP_PLACEMENT_TRIES (default 5; 1 = off) arenas, times the real sweep on
+// each - BOTH directions - and keeps the fastest (~0.1 s per try, once per context).  The arithmetic never sees the difference.
+//
+// Memory: a candidate is allocated while the best so far is still held (otherwise the allocator hands the same pages back),
+// so creation transiently needs up to TWO arenas; rejected candidates are kept as well while they fit into 85 % of what is
+// free (they keep the next candidate from landing where a slow one was) and are dropped first when they do not.  A lattice
+// whose second arena does not fit (cfg3, cfg5's and cfg4@2's slabs) is not searched at all.  Ranks that share one device
+// (rehearsals) should set EKPNP_PLACEMENT_TRIES=1: two searches at once can take each other's memory (bench.py does).
 static int placement_search(Ctx& c, size_t pitch, int nbuf) {
-  static const int tries_env = std::getenv("EKPNP_PLACEMENT_TRIES") ? std::atoi(std::getenv("EKPNP_PLACEMENT_TRIES")) : 3;
+  static const int tries_env = std::getenv("EKPNP_PLACEMENT_TRIES") ? std::atoi(std::getenv("EKPNP_PLACEMENT_TRIES")) : 5;
   const int zb = bulk_begin(c), ze = bulk_end(c);
   const size_t total = pitch * (size_t)nbuf;
   c.placement_tries = 0;
   c.placement_chosen = 0;
   if (tries_env <= 1 || ze - zb < 8 || c.nloc < (size_t)4 * 1024 * 1024) return EKPNP_OK;  // launch-bound lattices: nothing to gain
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return EKPNP_OK; }
-  int tries = tries_env > 8 ? 8 : tries_env;
-  while (tries > 1 && (double)total * (tries - 1) > 0.85 * (double)free_b) --tries;  // the candidates are held together
-  if (tries <= 1) return EKPNP_OK;
-  void* cand[8] = {c.pop_alloc[0][0]};
-  double best_ms[8] = {};
+  const int tries = tries_env > 8 ? 8 : tries_env;
+  auto fits = [&]() {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return (double)total <= 0.85 * (double)free_b;
+  };
+  if (!fits()) return EKPNP_OK;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   HIPCHK(c, hipEventCreate(&e0));
-  HIPCHK(c, hipEventCreate(&e1));
+  {
+    const hipError_t ee = hipEventCreate(&e1);
+    if (ee != hipSuccess) { (void)hipEventDestroy(e0); HIPCHK(c, ee); }
+  }
   auto point_at = [&](void* base) { carve_arena(c, base, pitch); };
   const bool streamed0 = c.streamed_state;
   c.streamed_state = false;  // time the kernel the steps run: pull + collide,
   c.e_phi_valid = lazy_efield_ok(c);  // E from phi (all zero here) where the steps will take it from phi
-  int n = 0;
+  void* cand[8] = {c.pop_alloc[0][0]};  // held allocations by try index (null: freed again or never made)
+  double best_ms[8] = {};
+  int n = 0, best = 0;
   hipError_t e = hipSuccess;
   for (; n < tries && e == hipSuccess; ++n) {
-    if (n > 0 && hipMalloc(&cand[n], total) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
+    if (n > 0) {
+      if (!fits()) {  // drop the rejected candidates, keep the best so far
+        for (int k = 0; k < n; ++k)
+          if (cand[k] && k != best) { (void)hipFree(cand[k]); cand[k] = nullptr; }
+        if (!fits()) break;
+      }
+      if (hipMalloc(&cand[n], total) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
+    }
     point_at(cand[n]);
     e = hipMemsetAsync(cand[n], 0, total, c.stream);
     // a step reads the buffers the step before wrote: BOTH directions (A -> B, B -> A; in place: down, up) are timed, two
@@ -931,27 +961,25 @@ static int placement_search(Ctx& c, size_t pitch, int nbuf) {
       c.cur ^= 1;
     }
     best_ms[n] = 0.5 * ((double)dir_ms[0] + (double)dir_ms[1]);
+    if (e == hipSuccess && best_ms[n] > 0.0 && (best_ms[best] <= 0.0 || best_ms[n] < best_ms[best])) best = n;
     if (std::getenv("EKPNP_DEBUG_ARENA")) std::fprintf(stderr, "ekpnp: arena %d: %.3f / %.3f ms per sweep in the two directions\n", n, dir_ms[0], dir_ms[1]);
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  int pick = 0;
-  for (int k = 1; k < n; ++k)
-    if (best_ms[k] > 0.0 && best_ms[k] < best_ms[pick]) pick = k;
   for (int k = 0; k < 8; ++k)
-    if (cand[k] && k != pick) (void)hipFree(cand[k]);
-  c.pop_alloc[0][0] = cand[pick];
-  point_at(cand[pick]);
+    if (cand[k] && k != best) (void)hipFree(cand[k]);
+  c.pop_alloc[0][0] = cand[best];
+  point_at(cand[best]);
   c.streamed_state = streamed0;
   c.e_phi_valid = false;
   c.cur = 0;
   c.rhs_ready = false;
   c.placement_tries = n;
-  c.placement_chosen = pick;
+  c.placement_chosen = best;
   for (int k = 0; k < 8; ++k) c.placement_ms[k] = k < n ? best_ms[k] : 0.0;
   // the probe sweeps wrote moments of an all-zero lattice (NaN) into the kept arena, the field arrays and the right-hand
   // side: all back to zero, which is what a context without a search starts from
-  if (e == hipSuccess) e = hipMemsetAsync(cand[pick], 0, total, c.stream);
+  if (e == hipSuccess) e = hipMemsetAsync(cand[best], 0, total, c.stream);
   for (int i = 0; i < EKPNP_NFIELDS && e == hipSuccess; ++i) e = hipMemsetAsync(c.fld[i], 0, c.nloc * sizeof(double), c.stream);
   if (e == hipSuccess) e = hipMemsetAsync(c.work, 0, c.nloc * sizeof(double), c.stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
@@ -959,7 +987,7 @@ static int placement_search(Ctx& c, size_t pitch, int nbuf) {
   HIPCHK(c, e);
   if (std::getenv("EKPNP_DEBUG_ARENA")) {
     std::fprintf(stderr, "ekpnp: placement search, %d arenas:", n);
-    for (int k = 0; k < n; ++k) std::fprintf(stderr, " %.3f%s", best_ms[k], k == pick ? "*" : "");
+    for (int k = 0; k < n; ++k) std::fprintf(stderr, " %.3f%s", best_ms[k], k == best ? "*" : "");
     std::fprintf(stderr, " ms per sweep\n");
   }
   return EKPNP_OK;
@@ -1168,6 +1196,10 @@ extern "C" int ekpnp_phi_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, s
 extern "C" int ekpnp_halo_pack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
+  if (c.halo_sent) {  // the boundary-plane launches stored their outgoing directions straight into the send buffers
+    c.halo_sent = false;
+    return EKPNP_OK;
+  }
   if (c.inplace) {
     if (c.collide_phase != 1) return fail(c, "in-place slab: ekpnp_halo_pack belongs between the boundary and the interior call");
     launch_halo_pack_stage(c);
@@ -1183,16 +1215,38 @@ extern "C" int ekpnp_halo_unpack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
   if (c.collide_phase != 0) return fail(c, "ekpnp_halo_unpack before ekpnp_collide_interior_planes");
+  if (c.halo_direct) {
+    // nothing is copied: the edge planes of the NEXT step pull straight out of the receive buffers (which the next exchange
+    // only overwrites after those launches); the ghost planes are filled on demand (ekpnp_save_checkpoint)
+    c.halo_recv_valid = true;
+    return EKPNP_OK;
+  }
   launch_halo_unpack(c);
   LAUNCHCHK(c);
   return EKPNP_OK;
 }
+
+namespace ekpnp {
+// the ghost planes of a slab, for whoever reads them instead of the receive buffers (the per-rank checkpoint)
+int ensure_ghost_planes(Ctx& c) {
+  if (!c.slab || !c.halo_recv_valid) return EKPNP_OK;
+  launch_halo_unpack(c);
+  LAUNCHCHK(c);
+  return EKPNP_OK;
+}
+}  // namespace ekpnp
 
 extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_stream_collide_save");
   if (c.collide_phase != 0) return fail(c, "ekpnp_collide_boundary_planes called twice");
   KArgs lo = c.kargs(), hi = lo;
+  if (c.halo_direct) {
+    // no pack / unpack copies: the edge launches write the send buffers and read the receive buffers themselves
+    lo.halo_out_dn = c.halo[0];
+    hi.halo_out_up = c.halo[1];
+    if (c.halo_recv_valid) { lo.halo_in_lo = c.halo[2]; hi.halo_in_hi = c.halo[3]; }
+  }
   if (c.inplace) {
     // redirect the stores of plane zg = 1 / zg = nzl into the staging planes 0 / 1
     for (int l = 0; l < c.p.n_lattices; ++l) {
@@ -1202,8 +1256,10 @@ extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
   }
   launch_collide_walls(c, lo, c.stream, true, false);
   launch_collide_walls(c, hi, c.stream, false, true);
-  if (c.z0 != 0) launch_collide_bulk(c, lo, 0, 1);
-  if (c.z0 + c.nzl != c.p.nz) launch_collide_bulk(c, hi, c.nzl - 1, c.nzl);
+  if (c.z0 != 0) { if (c.halo_direct) launch_collide_bulk_edge(c, lo, 0); else launch_collide_bulk(c, lo, 0, 1); }
+  if (c.z0 + c.nzl != c.p.nz) { if (c.halo_direct) launch_collide_bulk_edge(c, hi, c.nzl - 1); else launch_collide_bulk(c, hi, c.nzl - 1, c.nzl); }
+  c.halo_sent = c.halo_direct;
+  c.halo_recv_valid = false;  // consumed; the exchange that follows refills the buffers, ekpnp_halo_unpack says when
   c.collide_phase = 1;
   LAUNCHCHK(c);
   return EKPNP_OK;

@@ -95,7 +95,22 @@ struct KArgs {
   const double* phi_lo;        // phi plane below / above the slab (slab contexts), or null
   const double* phi_hi;
   double voltage, voltage2, dx, dy, dz;
+  // Slab edge planes without pack / unpack copies (round 4): the launches that collide a slab's first and last plane
+  // store their 9 outgoing directions ALSO straight into the send buffers (layout [lattice][9][ny][nx], k_halo_pack's),
+  // and pull their 9 incoming directions straight out of the receive buffers instead of a ghost plane.  Null: not a
+  // slab edge launch / the ghost planes are what is valid (after a checkpoint load, or EKPNP_HALO_DIRECT=0).
+  double* halo_out_dn;
+  double* halo_out_up;
+  const double* halo_in_lo;
+  const double* halo_in_hi;
 };
+
+// position of direction d among the 9 directions that cross a z face the way d does (up_dir / dn_dir): its slot in a halo buffer
+__host__ __device__ constexpr int halo_slot(int d) {
+  for (int k = 0; k < 9; ++k)
+    if (up_dir(k) == d || dn_dir(k) == d) return k;
+  return -1;
+}
 
 // Right-hand side of the Poisson equation on an interior plane, odd_extension's rows 1..NZ-2
 // (poisson.cu:121-135) in the reference's expression order: -F (c - cn)/eps, minus voltage/dz/dz on
@@ -134,6 +149,7 @@ void launch_init_equilibrium(Ctx&);
 void launch_collide_all(Ctx&);  // launch-bound lattices: plates and bulk in ONE launch (single two-buffer context)
 void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
 void launch_collide_bulk(Ctx&, const KArgs&, int zl_begin, int zl_end);
+void launch_collide_bulk_edge(Ctx&, const KArgs&, int zl);  // one slab edge plane: KArgs::halo_* honoured (EDGE kernels)
 void launch_collide_walls(Ctx&, const KArgs&, hipStream_t stream, bool lower, bool upper);
 void launch_halo_pack_stage(Ctx&);
 void launch_unstage(Ctx&);
@@ -149,6 +165,7 @@ int plane_fft_forward(Ctx&);    // fft_in() -> fft_spec(): the own kernels or th
 int plane_fft_inverse(Ctx&);    // fft_spec() -> fft_out()
 void launch_tridiag(Ctx&);
 bool tridiag_prepare_device();  // per-device function attributes of the partition z solves (current device)
+bool tridiag_pipe_prepare_device();  // ... of their pipelined forms (2 LDS images)
 void launch_phi_efield(Ctx&);
 void launch_slab_thomas_local(Ctx&);
 void launch_slab_reduce_correct(Ctx&);
@@ -233,6 +250,10 @@ struct Ctx {
   double* diag = nullptr;          // reduction scratch (DIAG_SCRATCH doubles)
   double* vwall = nullptr;         // {voltage, voltage, voltage2, voltage2}
   int collide_phase = 0;           // 0 idle, 1 boundary planes done
+  // slab edge planes without pack / unpack copies (KArgs::halo_*): knob, and where the current halos are
+  bool halo_direct = true;         // EKPNP_HALO_DIRECT=0: k_halo_pack / k_halo_unpack as in rounds 1-3 (the A/B partner)
+  bool halo_sent = false;          // the boundary-plane launches of this step have filled the send buffers already
+  bool halo_recv_valid = false;    // the receive buffers hold what the next pull of the edge planes needs (else: the ghost planes do)
   // hipGraph of two consecutive steps (A->B, B->A) for launch-bound lattices
   hipGraphExec_t graph2 = nullptr;
   int graph_cur = -1;              // value of `cur` the graph was captured at
@@ -241,6 +262,8 @@ struct Ctx {
   double2* fft_tw = nullptr;       // their twiddle table exp(-2 pi i k / 1024)
   hipfftHandle plan_fwd = 0, plan_inv = 0;
   bool tri_lds_ok = false;  // this context's device grants the partition z solves their dynamic LDS (tridiag_prepare_device)
+  bool tri_pipe = false;    // the partition z solves run pipelined (resident workgroups that prefetch the next mode group; EKPNP_TRI_PIPE, ekpnp_tune "tri_pipe")
+  int ncus = 0;             // compute units of the context's device (the grid of the pipelined z solves)
   int tri_partition = 1;  // z solve of a single context: 0 serial sweeps, 1 partition solve on large lattices, 2 wherever it applies
   bool have_fwd = false, have_inv = false;  // each handle is destroyed on its own (a failing second plan must not leak the first)
   bool plans = false;
@@ -267,6 +290,8 @@ struct Ctx {
 bool lazy_efield_ok(const Ctx& c);
 // capi.hip: bring the E arrays and phi's plates up to date if a lazy solve left them behind (no-op otherwise)
 int ensure_efield(Ctx& c);
+// capi.hip: fill a slab's ghost planes from the receive buffers if that is where the current halos are (checkpoint writers)
+int ensure_ghost_planes(Ctx& c);
 // capi.hip: phi or E are about to be overwritten from outside (set_field, readers): up to date first, then E is what the arrays say
 int efield_set_from_outside(Ctx& c);
 

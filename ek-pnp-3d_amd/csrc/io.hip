@@ -334,6 +334,8 @@ void io_ckpt_finish_load(Ctx& c, const CkptHeader& h) {
   c.t = h.time;
   c.rhs_ready = false;
   c.collide_phase = 0;
+  c.halo_sent = false;
+  c.halo_recv_valid = false;  // the loaded ghost planes are what the next pull of a slab's edge planes reads
 }
 }  // namespace ekpnp
 
@@ -341,6 +343,7 @@ extern "C" int ekpnp_save_checkpoint(ekpnp_ctx* ctx, const char* path) {
   NEEDCTX(ctx);
   if (!path) return fail(c, "NULL path");
   if (c.collide_phase != 0) return fail(c, "ekpnp_save_checkpoint between the boundary and the interior collide call");
+  if (int grc = ensure_ghost_planes(c)) return grc;  // a slab's file carries its ghost planes: the halos may still sit in the receive buffers
   HIPCHK(c, hipStreamSynchronize(c.stream));
   FILE* f = std::fopen(path, "wb");
   if (!f) return fail(c, "cannot open checkpoint file");

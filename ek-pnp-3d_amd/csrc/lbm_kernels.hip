@@ -161,7 +161,8 @@ __device__ __forceinline__ void equilibrium(const KArgs& a, double m, double vx,
 // (h: Ex, hn: Ey, temp - or f when there is no temperature lattice - Ez), shared through three more rows of the moment
 // image.  The kernel then reads phi(y-1), phi(y), phi(y+1), phi(z-1), phi(z+1): 24 bytes per node of HBM traffic like
 // the three E arrays (the y neighbours are L2 hits), and k_phi_efield (8 R + 24 W per node) drops out of the step.
-template <int NL, bool PULL, bool EPHI>
+// EDGE: the launch collides ONE plane, a slab's first or last: see KArgs::halo_*.
+template <int NL, bool PULL, bool EPHI, bool EDGE = false>
 __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, const int row, const int xb) {
   __shared__ double mom[EPHI ? 10 : 7][64];
   const int y = row % a.ny;
@@ -175,12 +176,23 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
   // source x for c_x = -1, 0, +1 (pull: x - c_x, periodic, LBM.cu:1970-1975)
   const unsigned xo[3] = {(unsigned)pop_xoff(xc + 1 == a.nx ? 0 : xc + 1), (unsigned)pop_xoff(xc), (unsigned)pop_xoff(xc == 0 ? a.nx - 1 : xc - 1)};
   const int ys[3] = {y + 1 == a.ny ? 0 : y + 1, y, y == 0 ? a.ny - 1 : y - 1};
+  // the same three source x as plain node indices (the halo buffers are dense [ny][nx] planes)
+  const int xr[3] = {xc + 1 == a.nx ? 0 : xc + 1, xc, xc == 0 ? a.nx - 1 : xc - 1};
 
   const double* __restrict__ src = a.A[lat];
   double f[Q];
   static_for<0, Q, 1>([&](auto ic) {
     constexpr int d = decltype(ic)::value;
     constexpr int cx = PULL ? ex_of(d) : 0, cy = PULL ? ey_of(d) : 0, cz = PULL ? ez_of(d) : 0;
+    if constexpr (EDGE && cz != 0) {
+      // a population that crosses the slab's face comes from the neighbouring slab: straight out of the receive buffer
+      // (the plane index is uniform over the launch, so this is a scalar branch)
+      const double* __restrict__ hb = cz > 0 ? a.halo_in_lo : a.halo_in_hi;
+      if (hb && zl == (cz > 0 ? 0 : a.nzl - 1)) {
+        f[d] = hb[((long long)lat * 9 + halo_slot(d)) * a.plane + (long long)ys[cy + 1] * a.nx + xr[cx + 1]];
+        return;
+      }
+    }
     const double* rowp = src + ((long long)(zg - cz) * a.ny + ys[cy + 1]) * a.rowstride + d * 64;
 #ifdef EKPNP_NT_LOADS  // A/B partner: non-temporal loads (every population is pulled exactly once) LOSE 3 %, profiles/r02_sweep_nt_loads.log
     f[d] = __builtin_nontemporal_load(rowp + xo[cx + 1]);
@@ -262,6 +274,11 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
 #else
     if (act) __builtin_nontemporal_store(v, dst + d * 64);
 #endif
+    if constexpr (EDGE && ez_of(d) != 0) {
+      // ... and one that leaves through the face goes into the send buffer as well (what k_halo_pack would copy there)
+      double* __restrict__ hb = ez_of(d) < 0 ? a.halo_out_dn : a.halo_out_up;
+      if (hb && act && zl == (ez_of(d) < 0 ? 0 : a.nzl - 1)) hb[((long long)lat * 9 + halo_slot(d)) * a.plane + (long long)y * a.nx + x] = v;
+    }
   };
   if (lat == 0) {
     if (act) {  // LBM.cu:807-810
@@ -305,12 +322,21 @@ __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(
   bulk_body<NL, PULL, EPHI>(a, zl_begin, row, xb);
 }
 
+// one plane, a slab's first or last (not a plate): halos straight to / from the exchange buffers
+template <int NL, bool PULL, bool EPHI>
+__global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_edge(const KArgs a, const int zl, const int nrows, const int nxb, const int rchunk) {
+  int xb;
+  const int row = bulk_row_of_block(nrows, nxb, rchunk, xb);
+  if (row < 0) return;
+  bulk_body<NL, PULL, EPHI, true>(a, zl, row, xb);
+}
+
 // ------------------------------------------------------------------------------------------
 // wall planes (global z = 0 and z = NZ-1): one thread per wall node, lattices in sequence.
 
 // pre-collision populations of lattice L at a node, as gpu_stream would have left them
 template <bool PULL>
-__device__ __forceinline__ void gather(const KArgs& a, const double* __restrict__ src, int x, int y, int zg, double (&f)[Q]) {
+__device__ __forceinline__ void gather(const KArgs& a, const int lat, const double* __restrict__ src, int x, int y, int zg, double (&f)[Q]) {
   const int xs[3] = {x + 1 == a.nx ? 0 : x + 1, x, x == 0 ? a.nx - 1 : x - 1};
   const int ys[3] = {y + 1 == a.ny ? 0 : y + 1, y, y == 0 ? a.ny - 1 : y - 1};
   static_for<0, Q, 1>([&](auto ic) {
@@ -321,6 +347,12 @@ __device__ __forceinline__ void gather(const KArgs& a, const double* __restrict_
       // gpu_stream's z wrap (LBM.cu:1972,1975): with zwrap the wall nodes read the opposite wall
       // plane directly instead of a ghost-plane copy of it
       if (a.zwrap) zs = zs == 0 ? a.nzl : (zs == a.nzl + 1 ? 1 : zs);
+      // slabs: what would be a ghost plane is the neighbouring slab's edge plane, read straight out of the receive buffer
+      const double* __restrict__ hb = zs == 0 ? a.halo_in_lo : (zs == a.nzl + 1 ? a.halo_in_hi : nullptr);
+      if (hb) {
+        f[d] = hb[((long long)lat * 9 + halo_slot(d)) * a.plane + (long long)ys[cy + 1] * a.nx + xs[cx + 1]];
+        return;
+      }
     }
     f[d] = src[((long long)zs * a.ny + ys[cy + 1]) * a.rowstride + d * 64 + pop_xoff(xs[cx + 1])];
   });
@@ -333,7 +365,7 @@ template <bool PULL>
 __device__ __forceinline__ void wall_scalar_pops(const KArgs& a, int lat, const double* __restrict__ src, int x, int y, int zg,
                                                  double TH_wall, double (&f)[Q]) {
   if constexpr (!PULL) {
-    gather<false>(a, src, x, y, zg, f);
+    gather<false>(a, lat, src, x, y, zg, f);
   } else {
     const long long o = ((long long)zg * a.ny + y) * a.rowstride + pop_xoff(x);
     static_for<0, Q, 1>([&](auto ic) {
@@ -344,84 +376,116 @@ __device__ __forceinline__ void wall_scalar_pops(const KArgs& a, int lat, const 
   }
 }
 
-// one wall node: plate `top` (0 lower, 1 upper), node (x, y); one thread, the lattices in sequence
+// One wall node per LANE, one lattice per WAVE (round 4; rounds 1-3: one thread did the lattices in sequence at 255 VGPRs,
+// one wave per SIMD, and gathered every scalar lattice twice - 0.44 ms for a 1024 x 1024 plate, half the HBM rate).  A
+// workgroup is NL wave64s over the same 64 wall nodes of plate `top` (0 lower, 1 upper; uniform over the workgroup), like
+// the bulk kernel: wave l gathers lattice l's pre-collision populations - and, on the lower plate, those of node z = 1 for
+// the velocity override -, the waves exchange their moments through LDS, then wave 0 reflects the fluid and waves 1.. collide
+// their scalar lattice out of the registers they already hold.  Same arithmetic per lattice in the same order: same bits.
 // EPHI (see bulk_body): on a plate phi is constant, so Ex = Ey = +0 (k_phi_efield forms 0.5*(v - v)/d there), and Ez is
 // gpu_bc's copy of the neighbouring interior plane's Ez (poisson.cu:57-69), formed from phi like that plane forms it.
 template <int NL, bool PULL, bool EPHI>
-__device__ __forceinline__ void wall_body(const KArgs& a, const int top, const int x, const int y) {
+__device__ __forceinline__ void wall_body(const KArgs& a, const int top, const int xraw, const int y) {
+  __shared__ double wmom[NL > 1 ? 13 : 1][64];  // rho, j(3), c, cn, T of the wall node; j(3), c, cn, T of node z = 1
+  const int lane = threadIdx.x & 63;
+  const int lat = NL > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const bool act = xraw < a.nx;
+  const int x = act ? xraw : a.nx - 1;
   const int zl = top ? a.nzl - 1 : 0;
   const int zg = zl + 1;
   const double TH_wall = top ? 0.0 : a.TH;  // LBM.cu:2226-2229 vs 2357-2412
   const long long sidx = ((long long)zl * a.ny + y) * (long long)a.nx + x;
   const long long orow = ((long long)zg * a.ny + y) * a.rowstride + pop_xoff(x);
 
+  // this wave's lattice at the wall node
   double f[Q];
-  gather<PULL>(a, a.A[0], x, y, zg, f);
-  const double rho = sum27(f);
-  double jx, jy, jz;
-  momentum(f, jx, jy, jz);
-  double ms[3] = {0.0, 0.0, 0.0};  // c, cn, T
-  {
-    double g[Q];
-    if constexpr (NL > 1) {
-      wall_scalar_pops<PULL>(a, 1, a.A[1], x, y, zg, TH_wall, g);
-      ms[0] = sum27(g);
-      wall_scalar_pops<PULL>(a, 2, a.A[2], x, y, zg, TH_wall, g);
-      ms[1] = sum27(g);
+  if (lat == 0) gather<PULL>(a, 0, a.A[0], x, y, zg, f);
+  else wall_scalar_pops<PULL>(a, lat, a.A[lat], x, y, zg, TH_wall, f);
+  double rho = 0.0, jx = 0.0, jy = 0.0, jz = 0.0;
+  double ms[3] = {0.0, 0.0, 0.0};              // c, cn, T
+  double j1x = 0.0, j1y = 0.0, j1z = 0.0;      // node z = 1 (lower plate only)
+  double m1[3] = {0.0, 0.0, 0.0};
+  if constexpr (NL > 1) {
+    if (lat == 0) {
+      momentum(f, jx, jy, jz);
+      wmom[0][lane] = sum27(f);
+      wmom[1][lane] = jx;
+      wmom[2][lane] = jy;
+      wmom[3][lane] = jz;
+    } else {
+      wmom[3 + lat][lane] = sum27(f);
     }
-    if constexpr (NL > 3) {
-      wall_scalar_pops<PULL>(a, 3, a.A[3], x, y, zg, TH_wall, g);
-      ms[2] = sum27(g);
+    if (!top) {
+      // z == 0 override, LBM.cu:663-801: node z=1's pre-collision populations
+      double g[Q];
+      gather<PULL>(a, lat, a.A[lat], x, y, zg + 1, g);
+      if (lat == 0) {
+        momentum(g, j1x, j1y, j1z);
+        wmom[7][lane] = j1x;
+        wmom[8][lane] = j1y;
+        wmom[9][lane] = j1z;
+      } else {
+        wmom[9 + lat][lane] = sum27(g);
+      }
+    }
+    __syncthreads();
+    rho = wmom[0][lane];
+    jx = wmom[1][lane];
+    jy = wmom[2][lane];
+    jz = wmom[3][lane];
+    ms[0] = wmom[4][lane];
+    ms[1] = wmom[5][lane];
+    if constexpr (NL > 3) ms[2] = wmom[6][lane];
+    if (!top) {
+      j1x = wmom[7][lane];
+      j1y = wmom[8][lane];
+      j1z = wmom[9][lane];
+      m1[0] = wmom[10][lane];
+      m1[1] = wmom[11][lane];
+      if constexpr (NL > 3) m1[2] = wmom[12][lane];
+    }
+  } else {
+    rho = sum27(f);
+    momentum(f, jx, jy, jz);
+    if (!top) {
+      double g[Q];
+      gather<PULL>(a, 0, a.A[0], x, y, zg + 1, g);
+      momentum(g, j1x, j1y, j1z);
     }
   }
   double Ex = 0.0, Ey = 0.0, Ez = 0.0;
+  double E1x = 0.0, E1y = 0.0, E1z = 0.0;
   if constexpr (NL > 1) {
     if constexpr (EPHI) {
       const double* __restrict__ ph = a.fld[EKPNP_PHI];
       const long long oc = (long long)y * a.nx + x;
       // plane 1 / NZ-2: 0.5*(phi(z-1) - phi(z+1))/dz with the plate's pinned value on one side
       Ez = top ? 0.5 * (ph[(long long)(a.nzl - 3) * a.plane + oc] - a.voltage2) / a.dz : 0.5 * (a.voltage - ph[2 * a.plane + oc]) / a.dz;
+      if (!top) {
+        const double* __restrict__ p1 = ph + a.plane;  // plane 1
+        const int xm = x == 0 ? a.nx - 1 : x - 1, xp = x + 1 == a.nx ? 0 : x + 1;
+        const int ym = y == 0 ? a.ny - 1 : y - 1, yp = y + 1 == a.ny ? 0 : y + 1;
+        E1x = 0.5 * (p1[(long long)y * a.nx + xm] - p1[(long long)y * a.nx + xp]) / a.dx;
+        E1y = 0.5 * (p1[(long long)ym * a.nx + x] - p1[(long long)yp * a.nx + x]) / a.dy;
+        E1z = Ez;  // Ez(0) is the copy of Ez(1)
+      }
     } else {
       Ex = a.fld[EKPNP_EX][sidx];
       Ey = a.fld[EKPNP_EY][sidx];
       Ez = a.fld[EKPNP_EZ][sidx];
+      if (!top) {
+        const long long s1 = sidx + a.plane;
+        E1x = a.fld[EKPNP_EX][s1];
+        E1y = a.fld[EKPNP_EY][s1];
+        E1z = a.fld[EKPNP_EZ][s1];
+      }
     }
   }
   const double rhoinv = 1.0 / rho;
   const double hdt = a.dt * 0.5;
   double ux, uy, uz;
   if (!top) {
-    // z == 0 override, LBM.cu:663-801: minus the velocity formula evaluated with node z=1's
-    // pre-collision populations, field and moments, but with 1/rho of node z=0 (LBM.cu:780).
-    double g[Q];
-    gather<PULL>(a, a.A[0], x, y, zg + 1, g);
-    double j1x, j1y, j1z;
-    momentum(g, j1x, j1y, j1z);
-    double m1[3] = {0.0, 0.0, 0.0};
-    double E1x = 0.0, E1y = 0.0, E1z = 0.0;
-    if constexpr (NL > 1) {
-      gather<PULL>(a, a.A[1], x, y, zg + 1, g);
-      m1[0] = sum27(g);
-      gather<PULL>(a, a.A[2], x, y, zg + 1, g);
-      m1[1] = sum27(g);
-      const long long s1 = sidx + a.plane;
-      if constexpr (EPHI) {
-        const double* __restrict__ p1 = a.fld[EKPNP_PHI] + a.plane;  // plane 1
-        const int xm = x == 0 ? a.nx - 1 : x - 1, xp = x + 1 == a.nx ? 0 : x + 1;
-        const int ym = y == 0 ? a.ny - 1 : y - 1, yp = y + 1 == a.ny ? 0 : y + 1;
-        E1x = 0.5 * (p1[(long long)y * a.nx + xm] - p1[(long long)y * a.nx + xp]) / a.dx;
-        E1y = 0.5 * (p1[(long long)ym * a.nx + x] - p1[(long long)yp * a.nx + x]) / a.dy;
-        E1z = Ez;  // Ez(0) is the copy of Ez(1)
-      } else {
-        E1x = a.fld[EKPNP_EX][s1];
-        E1y = a.fld[EKPNP_EY][s1];
-        E1z = a.fld[EKPNP_EZ][s1];
-      }
-    }
-    if constexpr (NL > 3) {
-      gather<PULL>(a, a.A[3], x, y, zg + 1, g);
-      m1[2] = sum27(g);
-    }
+    // minus the velocity formula evaluated with node z=1's populations, field and moments, but with 1/rho of node z=0 (LBM.cu:780)
     const Force F1 = body_force(a, m1[0], m1[1], m1[2], E1x, E1y, E1z);
     ux = -velocity(rhoinv, j1x, a.cflinv, F1.x, hdt);
     uy = -velocity(rhoinv, j1y, a.cflinv, F1.y, hdt);
@@ -432,20 +496,20 @@ __device__ __forceinline__ void wall_body(const KArgs& a, const int top, const i
     uy = velocity(rhoinv, jy, a.cflinv, F.y, hdt);
     uz = velocity(rhoinv, jz, a.cflinv, F.z, hdt);
   }
-  a.fld[EKPNP_RHO][sidx] = rho;
-  a.fld[EKPNP_UX][sidx] = ux;
-  a.fld[EKPNP_UY][sidx] = uy;
-  a.fld[EKPNP_UZ][sidx] = uz;
-  if constexpr (NL > 1) {
-    a.fld[EKPNP_C][sidx] = ms[0];
-    a.fld[EKPNP_CN][sidx] = ms[1];
-  }
-  if constexpr (NL > 3) a.fld[EKPNP_T][sidx] = ms[2];
-  if (a.rhs) a.rhs[sidx] = 0.0;  // wall planes carry no Poisson unknown (poisson.cu:116-119,136-139)
-
-  // fluid: gpu_boundary (LBM.cu:1848-1961) discards the wall collision: f0 <- pre-collision f0,
-  // f2[d] <- pre-collision f1[opp d] (+ moving-wall terms on the upper plate).
-  {
+  // a plate that is a slab's edge plane sends its outgoing populations (the wall-to-wall ghost loop of gpu_stream,
+  // LBM.cu:1972,1975) like any edge plane: also straight into the send buffer (KArgs::halo_out_*)
+  double* __restrict__ const hout = top ? a.halo_out_up : a.halo_out_dn;
+  const long long hnode = (long long)y * a.nx + x;
+  if (lat == 0) {
+    if (act) {
+      a.fld[EKPNP_RHO][sidx] = rho;
+      a.fld[EKPNP_UX][sidx] = ux;
+      a.fld[EKPNP_UY][sidx] = uy;
+      a.fld[EKPNP_UZ][sidx] = uz;
+      if (a.rhs) a.rhs[sidx] = 0.0;  // wall planes carry no Poisson unknown (poisson.cu:116-119,136-139)
+    }
+    // fluid: gpu_boundary (LBM.cu:1848-1961) discards the wall collision: f0 <- pre-collision f0,
+    // f2[d] <- pre-collision f1[opp d] (+ moving-wall terms on the upper plate).
     double* __restrict__ dst = a.B[0];
     static_for<0, Q, 1>([&](auto ic) {
       constexpr int d = decltype(ic)::value;
@@ -454,40 +518,38 @@ __device__ __forceinline__ void wall_body(const KArgs& a, const int top, const i
         constexpr int sgn = (ex_of(d) > 0 || d == 3) ? 1 : (ex_of(d) < 0 ? -1 : 0);  // LBM.cu:1902-1927
         if constexpr (sgn != 0) v = v + sgn * (a.uw_multi * w_of(d));
       }
-      dst[d * 64 + orow] = v;
+      if (act) dst[d * 64 + orow] = v;
+      if constexpr (ez_of(d) != 0) {
+        if (hout && act && (ez_of(d) > 0) == (top != 0)) hout[(long long)halo_slot(d) * a.plane + hnode] = v;
+      }
     });
-  }
-  // ions and temperature collide on the wall like anywhere else (their post-collision values
-  // are what gpu_bc_charge reflects in the next step).
-  if constexpr (NL > 1) {
-    static_for<1, NL, 1>([&](auto lc) {
-      constexpr int lat = decltype(lc)::value;
-      double g[Q];
-      wall_scalar_pops<PULL>(a, lat, a.A[lat], x, y, zg, TH_wall, g);
-      double* __restrict__ dst = a.B[lat];
-      auto store = [&](auto ic, double v) {
-        constexpr int d = decltype(ic)::value;
-        dst[d * 64 + orow] = v;
-      };
-      const double k = a.mob[lat];
-      collide_scalar(a, g, ms[lat - 1], ux + k * Ex, uy + k * Ey, uz + k * Ez, a.wp[lat], a.wm[lat], store);
-    });
+  } else {
+    // ions and temperature collide on the wall like anywhere else (their post-collision values
+    // are what gpu_bc_charge reflects in the next step)
+    if (act) a.fld[lat == 1 ? EKPNP_C : lat == 2 ? EKPNP_CN : EKPNP_T][sidx] = ms[lat - 1];
+    double* __restrict__ dst = a.B[lat];
+    auto store = [&](auto ic, double v) {
+      constexpr int d = decltype(ic)::value;
+      if (act) dst[d * 64 + orow] = v;
+      if constexpr (ez_of(d) != 0) {
+        if (hout && act && (ez_of(d) > 0) == (top != 0)) hout[((long long)lat * 9 + halo_slot(d)) * a.plane + hnode] = v;
+      }
+    };
+    const double k = a.mob[lat];
+    collide_scalar(a, f, ms[lat - 1], ux + k * Ex, uy + k * Ey, uz + k * Ez, a.wp[lat], a.wm[lat], store);
   }
 }
 
 template <int NL, bool PULL, bool EPHI>
-__global__ void __launch_bounds__(64) k_collide_wall(const KArgs a, const int first_wall) {
+__global__ void __launch_bounds__(64 * NL) k_collide_wall(const KArgs a, const int first_wall) {
   // one launch covers the walls this context owns: blockIdx.z = 0 is wall `first_wall`
   // (0 lower plate, 1 upper plate), blockIdx.z = 1 the upper plate
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  if (x >= a.nx) return;
-  wall_body<NL, PULL, EPHI>(a, first_wall + (int)blockIdx.z, x, (int)blockIdx.y);
+  wall_body<NL, PULL, EPHI>(a, first_wall + (int)blockIdx.z, (int)(blockIdx.x * 64 + (threadIdx.x & 63)), (int)blockIdx.y);
 }
 
 // Launch-bound lattices (the reference's own 50x8x51: wall planes 12 us, bulk 10 us, both pure latency):
-// ONE launch for the whole lattice.  The rows beyond the bulk rows are the plates' rows; there the first
-// wave of the workgroup does the wall nodes and the other waves leave (the row, hence the branch, is
-// uniform over the workgroup, so the barrier of the bulk path is never reached by a part of a workgroup).
+// ONE launch for the whole lattice.  The rows beyond the bulk rows are the plates' rows (the row, hence the branch, is
+// uniform over the workgroup, so every barrier is reached by whole workgroups).
 template <int NL, bool PULL, bool EPHI>
 __global__ void __launch_bounds__(64 * NL) k_collide_all(const KArgs a, const int zl_begin, const int nrows_bulk, const int nxb, const int rchunk) {
   int xb;
@@ -496,11 +558,8 @@ __global__ void __launch_bounds__(64 * NL) k_collide_all(const KArgs a, const in
   if (row < nrows_bulk) {
     bulk_body<NL, PULL, EPHI>(a, zl_begin, row, xb);
   } else {
-    if (threadIdx.x >= 64) return;
     const int w = row - nrows_bulk;  // [0, ny): lower plate, [ny, 2 ny): upper plate
-    const int x = xb * 64 + (int)threadIdx.x;
-    if (x >= a.nx) return;
-    wall_body<NL, PULL, EPHI>(a, w / a.ny, x, w % a.ny);
+    wall_body<NL, PULL, EPHI>(a, w / a.ny, xb * 64 + (int)(threadIdx.x & 63), w % a.ny);
   }
 }
 
@@ -703,6 +762,30 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
 }
 
 template <int NL>
+static void edge_dispatch(Ctx& c, const KArgs& a, int zl) {
+  const int nrows = c.p.ny, nxb = (c.p.nx + 63) / 64, rchunk = 64;
+  const long long per_xcd = ((long long)nrows + 8LL * rchunk - 1) / (8LL * rchunk) * rchunk;
+  dim3 g((unsigned)(8 * per_xcd * nxb)), b(64 * NL);
+  const bool ephi = collide_takes_e_from_phi(c);
+  if (c.streamed_state) {
+    if (ephi) hipLaunchKernelGGL((k_collide_edge<NL, false, (NL > 1)>), g, b, 0, c.stream, a, zl, nrows, nxb, rchunk);
+    else hipLaunchKernelGGL((k_collide_edge<NL, false, false>), g, b, 0, c.stream, a, zl, nrows, nxb, rchunk);
+  } else {
+    if (ephi) hipLaunchKernelGGL((k_collide_edge<NL, true, (NL > 1)>), g, b, 0, c.stream, a, zl, nrows, nxb, rchunk);
+    else hipLaunchKernelGGL((k_collide_edge<NL, true, false>), g, b, 0, c.stream, a, zl, nrows, nxb, rchunk);
+  }
+  note_launch(c, "k_collide_edge");
+}
+
+void launch_collide_bulk_edge(Ctx& c, const KArgs& a, int zl) {
+  switch (c.p.n_lattices) {
+    case 1: edge_dispatch<1>(c, a, zl); break;
+    case 3: edge_dispatch<3>(c, a, zl); break;
+    default: edge_dispatch<4>(c, a, zl); break;
+  }
+}
+
+template <int NL>
 static void all_dispatch(Ctx& c, const KArgs& a) {
   const int nrows_bulk = (c.nzl - 2) * c.p.ny, nrows = nrows_bulk + 2 * c.p.ny;
   const int nxb = (c.p.nx + 63) / 64, rchunk = 64;
@@ -741,7 +824,7 @@ void launch_collide_bulk(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
 
 template <int NL>
 static void wall_dispatch(Ctx& c, const KArgs& a, int first_wall, int nwalls, hipStream_t stream) {
-  dim3 g((unsigned)((c.p.nx + 63) / 64), (unsigned)c.p.ny, (unsigned)nwalls), b(64);
+  dim3 g((unsigned)((c.p.nx + 63) / 64), (unsigned)c.p.ny, (unsigned)nwalls), b(64 * NL);
   const bool ephi = collide_takes_e_from_phi(c);
   if (c.streamed_state) {
     if (ephi) hipLaunchKernelGGL((k_collide_wall<NL, false, (NL > 1)>), g, b, 0, stream, a, first_wall);

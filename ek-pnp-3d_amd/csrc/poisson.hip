@@ -254,34 +254,61 @@ __device__ __forceinline__ double recip(double x) {
 // R = 8 kernel moves in 0.56.  With LANES = 16 (32) a wavefront holds 4 (2) modes of 16 R (32 R) rows, the reduction has
 // 4 (5) levels and serves all of them at once, and a workgroup covers 32 (16) adjacent modes: 512 (256) contiguous
 // bytes per row.
-template <int R, int LANES, bool SLAB>
-__device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __restrict__ rows, const int n, const double* __restrict__ bound) {
-  constexpr int MPW = 64 / LANES;        // modes per wavefront
-  constexpr int MC = 8 * MPW;            // modes (LDS columns) per workgroup of 8 wavefronts
+// ---- the pieces of the partition solve (shared by the one-shot kernels and the pipelined ones below) ---------------------
+template <int R, int LANES>
+struct TriPart {
+  static constexpr int MPW = 64 / LANES;        // modes per wavefront
+  static constexpr int MC = 8 * MPW;            // modes (LDS columns) per workgroup of 8 wavefronts
   static_assert(LANES * R <= 512 && 64 % LANES == 0, "a column has LANES x R row slots");
-  constexpr int TR = 512 / MC;           // rows loaded per pass of the workgroup
-  constexpr int FM = (MC < 16 ? MC : 16) - 1;  // the column index is XOR-ed with the owning lane (mod 16 columns = 256 bytes of banks)
-  extern __shared__ double2 tp_lds[];    // [LANES R slots][MC columns] = R x 8 KB
-  const long long ms = (long long)a.ny * a.nxh;
-  const long long m0 = (long long)blockIdx.x * MC;
-  {
+  static constexpr int TR = 512 / MC;           // rows loaded per pass of the workgroup
+  static constexpr int FM = (MC < 16 ? MC : 16) - 1;  // the column index is XOR-ed with the owning lane (mod 16 columns = 256 bytes of banks)
+  static constexpr int IMAGE = LANES * R * MC;  // double2 elements of one LDS image [LANES R slots][MC columns] = R x 8 KB
+
+  // the workgroup's rows of mode group m0 .. m0 + MC - 1, coalesced (thread (c, t): rows t + TR r of column c), into registers
+  static __device__ __forceinline__ void load(const double2* __restrict__ rows, long long ms, long long m0, int n, double2 (&v)[R]) {
     const int c = threadIdx.x % MC, t = threadIdx.x / MC;
     const double2* src = rows + m0 + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s = t + TR * r;
-      double2 v = make_double2(0.0, 0.0);
-      if (s < n) v = src[(long long)s * ms];
-      tp_lds[s * MC + (c ^ ((s / R) & FM))] = v;
+      v[r] = make_double2(0.0, 0.0);
+      if (s < n) v[r] = src[(long long)s * ms];
     }
   }
-  __syncthreads();
+  // registers -> LDS image (the rows change owner there)
+  static __device__ __forceinline__ void put(double2* __restrict__ img, const double2 (&v)[R]) {
+    const int c = threadIdx.x % MC, t = threadIdx.x / MC;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int s = t + TR * r;
+      img[s * MC + (c ^ ((s / R) & FM))] = v[r];
+    }
+  }
+  // LDS image -> global, the way the rows came
+  static __device__ __forceinline__ void store(double2* __restrict__ rows, long long ms, long long m0, int n, const double2* __restrict__ img) {
+    const int c = threadIdx.x % MC, t = threadIdx.x / MC;
+    double2* dst = rows + m0 + c;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int s = t + TR * r;
+      if (s < n) TRI_STORE(dst + (long long)s * ms, img[s * MC + (c ^ ((s / R) & FM))]);
+    }
+  }
+};
+
+// the solve proper, on an LDS image: every lane takes its R rows out of the image, eliminates, takes part in the cyclic
+// reduction of the interface rows and puts its R solution rows back
+template <int R, int LANES, bool SLAB>
+__device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __restrict__ img, const long long m0, const int n, const double* __restrict__ bound) {
+  using TP = TriPart<R, LANES>;
+  constexpr int MPW = TP::MPW, MC = TP::MC, FM = TP::FM;
+  const long long ms = (long long)a.ny * a.nxh;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l = lane % LANES;                 // lane within its mode: owns slots R l .. R l + R - 1
   const int col = w * MPW + lane / LANES;     // the mode among the workgroup's MC
   const double b = mode_diag((int)(m0 + col), a.ny, a.nxh, a.Lx, a.Ly, a.dz);
   const double dz2 = a.dz * a.dz;
-  double2* mine = tp_lds + (R * l) * MC + (col ^ (l & FM));
+  double2* mine = img + (R * l) * MC + (col ^ (l & FM));
   double2 g[R];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
@@ -365,15 +392,57 @@ __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __res
   for (int k = 0; k < R - 1; ++k)
     mine[k * MC] = make_double2((g[k].x - ylx * v[k] - yx * wv[k]) * a.inv_nxny, (g[k].y - yly * v[k] - yy * wv[k]) * a.inv_nxny);
   mine[(R - 1) * MC] = make_double2(yx * a.inv_nxny, yy * a.inv_nxny);
-  __syncthreads();
+}
+
+template <int R, int LANES, bool SLAB>
+__device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __restrict__ rows, const int n, const double* __restrict__ bound) {
+  using TP = TriPart<R, LANES>;
+  extern __shared__ double2 tp_lds[];    // [LANES R slots][MC columns] = R x 8 KB
+  const long long ms = (long long)a.ny * a.nxh;
+  const long long m0 = (long long)blockIdx.x * TP::MC;
   {
-    const int c = threadIdx.x % MC, t = threadIdx.x / MC;
-    double2* dst = rows + m0 + c;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int s = t + TR * r;
-      if (s < n) TRI_STORE(dst + (long long)s * ms, tp_lds[s * MC + (c ^ ((s / R) & FM))]);
-    }
+    double2 v[R];
+    TP::load(rows, ms, m0, n, v);
+    TP::put(tp_lds, v);
+  }
+  __syncthreads();
+  tridiag_part_solve<R, LANES, SLAB>(a, tp_lds, m0, n, bound);
+  __syncthreads();
+  TP::store(rows, ms, m0, n, tp_lds);
+}
+
+// Pipelined form (round 4).  Counters of the one-shot kernel on cfg3 (profiles/r04_cfg3_pmc_sq_lds_tcc.json, k_tridiag_part<8,64>):
+// the waves are PARKED at a waitcnt or a barrier for 66 % of their cycles and issue instructions for 13.5 % (VALU 8.1 %, LDS
+// 4.3 %; LDS bank conflicts 4 % of the LDS cycles): neither arithmetic nor LDS bounds it - each workgroup loads, THEN computes,
+// THEN stores, and two workgroups per CU (64 KB of LDS each) do not interleave those phases: 2.2 GB in 0.55 ms = 4.0 TB/s.
+// Here ONE workgroup per CU stays resident and walks over the mode groups g = blockIdx.x, + gridDim.x, ...: the rows of
+// group g + gridDim.x are requested (into registers) BEFORE group g is solved and land during the solve, the solution of
+// group g is stored while the next iteration runs, and two LDS images (2 x 64 KB) take turns so that one barrier pair per
+// group suffices.  Plain global loads survive __syncthreads() (a bare s_barrier when no LDS-DMA is in flight).
+// Same arithmetic on the same data in the same order as the one-shot kernel: bit-identical results.
+template <int R, int LANES, bool SLAB>
+__device__ __forceinline__ void tridiag_pipe_body(const PArgs& a, double2* __restrict__ rows, const int n, const double* __restrict__ bound, const int ngroups) {
+  using TP = TriPart<R, LANES>;
+  extern __shared__ double2 tp_lds[];    // two images
+  const long long ms = (long long)a.ny * a.nxh;
+  int g = blockIdx.x;
+  if (g >= ngroups) return;              // whole workgroup
+  double2 v[R];
+  TP::load(rows, ms, (long long)g * TP::MC, n, v);
+  int buf = 0;
+  for (; g < ngroups; g += gridDim.x) {
+    double2* img = tp_lds + buf * TP::IMAGE;
+    const long long m0 = (long long)g * TP::MC;
+    TP::put(img, v);
+    const int gn = g + gridDim.x;
+    if (gn < ngroups) TP::load(rows, ms, (long long)gn * TP::MC, n, v);  // in flight during the solve below
+    __syncthreads();
+    tridiag_part_solve<R, LANES, SLAB>(a, img, m0, n, bound);
+    __syncthreads();
+    TP::store(rows, ms, m0, n, img);
+    // the image written next is the OTHER one; this one is written again only after the two barriers of the next
+    // iteration, which every thread passes after its reads here
+    buf ^= 1;
   }
 }
 
@@ -386,6 +455,16 @@ __global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
 template <int R, int LANES = 64>
 __global__ void __launch_bounds__(512) k_slab_part(PArgs a, int row_a, int m, const double* __restrict__ bound) {
   tridiag_part_body<R, LANES, true>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound);
+}
+
+// the pipelined forms: one resident workgroup per CU (two waves per SIMD: the register file is theirs), 2 x R x 8 KB of LDS
+template <int R, int LANES = 64>
+__global__ void __launch_bounds__(512, 2) k_tridiag_pipe(PArgs a, int ngroups) {
+  tridiag_pipe_body<R, LANES, false>(a, a.spec + (long long)a.ny * a.nxh, a.nz - 2, nullptr, ngroups);
+}
+template <int R, int LANES = 64>
+__global__ void __launch_bounds__(512, 2) k_slab_pipe(PArgs a, int row_a, int m, const double* __restrict__ bound, int ngroups) {
+  tridiag_pipe_body<R, LANES, true>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound, ngroups);
 }
 
 // Short channels (NZ - 2 <= 64 unknown rows, e.g. the reference's own 51 planes): the serial
@@ -721,8 +800,11 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __r
 // stage 1 of the read-once slab solve (round 3): ONLY the two edge values, as dot products.  A is symmetric and
 // persymmetric, so  p_1 = e_1^T A^-1 r = u . r  and  p_m = e_m^T A^-1 r = sum_j u_j r_{m+1-j}:  no recurrence, no
 // checkpoint rows, and - u_j decays like lambda^j, lambda = the small root of  lambda^2 + b lambda + 1 = 0  -
-// only the K rows at either end of the block where u_j is not below 2^-66 of u_1 (a term beyond is less than a
-// rounding error of the sum).  The lowest modes (b -> -2, lambda -> 1) need every row, a mid-range mode a few
+// only the K rows at either end of the block where u_j is not below 2^-66 of u_1.  The bound is ABSOLUTE: a dropped term
+// is |u_j r_j| <= 2^-66 |u_1| max|r|, i.e. what is neglected in p_1 (p_m) is below 2^-66 m of |u_1| max|r| - a rounding
+// error of the edge value whenever the edge value is of the size of u_1 max|r|, and in any case ~1e-20 of the field's scale
+// (it is NOT relative to the kept sum: with charge confined to the planes next to one plate the kept terms of the far
+// edge's p can be smaller than a dropped one; tests/test_group_gpu.py::test_slab_edge_values_with_charge_at_one_plate).  The lowest modes (b -> -2, lambda -> 1) need every row, a mid-range mode a few
 // dozen: on a 512-plane slab the kernel touches ~1/6 of the spectrum instead of all of it.  Workgroup = 64 adjacent
 // modes x EDGE_SEGS segments of the K rows (the longest K of the 64 modes), partial sums combined through LDS.
 constexpr int EDGE_SEGS = 16;  // 4 measured first: 0.133 ms on a 512-plane slab, the low modes' 128 dependent rows per thread being the critical path
@@ -1003,23 +1085,25 @@ void launch_slab_reduce_correct(Ctx& c) {
   note_launch(c, "k_slab_interface");
   if (slab_read_once(c)) {
     const int m = c.slab_m;
-    // short columns: several modes per wavefront (tridiag_part_body's LANES) where the mode count allows whole workgroups
-    if (m <= 128 && wide_modes() && nm % 32 == 0) {
-      hipLaunchKernelGGL((k_slab_part<8, 16>), dim3(nm / 32), dim3(512), 8 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
-      note_launch(c, "k_slab_part<8,16>");
-    } else if (m <= 128) {
-      hipLaunchKernelGGL((k_slab_part<2, 64>), dim3(nm / 8), dim3(512), 2 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
-      note_launch(c, "k_slab_part<2>");
-    } else if (m <= 256 && wide_modes() && nm % 16 == 0) {
-      hipLaunchKernelGGL((k_slab_part<8, 32>), dim3(nm / 16), dim3(512), 8 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
-      note_launch(c, "k_slab_part<8,32>");
-    } else if (m <= 256) {
-      hipLaunchKernelGGL((k_slab_part<4, 64>), dim3(nm / 8), dim3(512), 4 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
-      note_launch(c, "k_slab_part<4>");
-    } else {
-      hipLaunchKernelGGL((k_slab_part<8, 64>), dim3(nm / 8), dim3(512), 8 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
-      note_launch(c, "k_slab_part<8>");
-    }
+    // one-shot kernel (a workgroup per mode group) or, c.tri_pipe, the pipelined form (resident workgroups that prefetch)
+#define SLAB_PART(RR, LL, GROUP, NAME)                                                                                           \
+    do {                                                                                                                         \
+      if (c.tri_pipe) {                                                                                                          \
+        const int ng = nm / (GROUP);                                                                                             \
+        hipLaunchKernelGGL((k_slab_pipe<RR, LL>), dim3(ng < c.ncus ? ng : c.ncus), dim3(512), 2 * (RR) * 8192, c.stream, a, c.slab_row_a, m, c.edge_local, ng); \
+        note_launch(c, "k_slab_pipe<" NAME ">");                                                                                 \
+      } else {                                                                                                                   \
+        hipLaunchKernelGGL((k_slab_part<RR, LL>), dim3(nm / (GROUP)), dim3(512), (RR) * 8192, c.stream, a, c.slab_row_a, m, c.edge_local); \
+        note_launch(c, "k_slab_part<" NAME ">");                                                                                 \
+      }                                                                                                                          \
+    } while (0)
+    // short columns: several modes per wavefront (LANES of the partition solve) where the mode count allows whole workgroups
+    if (m <= 128 && wide_modes() && nm % 32 == 0) SLAB_PART(8, 16, 32, "8,16");
+    else if (m <= 128) SLAB_PART(2, 64, 8, "2");
+    else if (m <= 256 && wide_modes() && nm % 16 == 0) SLAB_PART(8, 32, 16, "8,32");
+    else if (m <= 256) SLAB_PART(4, 64, 8, "4");
+    else SLAB_PART(8, 64, 8, "8");
+#undef SLAB_PART
     return;
   }
   hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.edge_local, c.slab_w);
@@ -1058,6 +1142,37 @@ bool tridiag_prepare_device() {
   return true;
 }
 
+// ... and of the pipelined forms (two LDS images: up to 128 KB of the CU's 160 KB)
+bool tridiag_pipe_prepare_device() {
+  hipError_t e = hipSuccess;
+  auto lds = [&](const void* fn, int bytes) {
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  };
+  lds(reinterpret_cast<const void*>(&k_tridiag_pipe<8, 64>), 16 * 8192);
+  lds(reinterpret_cast<const void*>(&k_tridiag_pipe<4, 64>), 8 * 8192);
+  lds(reinterpret_cast<const void*>(&k_tridiag_pipe<8, 32>), 16 * 8192);
+  lds(reinterpret_cast<const void*>(&k_tridiag_pipe<8, 16>), 16 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_pipe<8, 64>), 16 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_pipe<4, 64>), 8 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_pipe<2, 64>), 4 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_pipe<8, 32>), 16 * 8192);
+  lds(reinterpret_cast<const void*>(&k_slab_pipe<8, 16>), 16 * 8192);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
+}
+
+// one-shot kernel (a workgroup per mode group) or, c.tri_pipe, the pipelined form (resident workgroups that prefetch)
+#define TRI_PART(RR, LL, GROUP, NAME)                                                                                            \
+    do {                                                                                                                         \
+      if (c.tri_pipe) {                                                                                                          \
+        const int ng = nm / (GROUP);                                                                                             \
+        hipLaunchKernelGGL((k_tridiag_pipe<RR, LL>), dim3(ng < c.ncus ? ng : c.ncus), dim3(512), 2 * (RR) * 8192, c.stream, a, ng); \
+        note_launch(c, "k_tridiag_pipe<" NAME ">");                                                                              \
+      } else {                                                                                                                   \
+        hipLaunchKernelGGL((k_tridiag_part<RR, LL>), dim3(nm / (GROUP)), dim3(512), (RR) * 8192, c.stream, a);                   \
+        note_launch(c, "k_tridiag_part<" NAME ">");                                                                              \
+      }                                                                                                                          \
+    } while (0)
 void launch_tridiag(Ctx& c) {
   PArgs a = c.pargs();
   const int nm = c.p.ny * c.nxh;
@@ -1071,22 +1186,20 @@ void launch_tridiag(Ctx& c) {
     hipLaunchKernelGGL(k_tridiag_pcr64, dim3((nm + 3) / 4), dim3(256), 0, c.stream, a);
     note_launch(c, "k_tridiag_pcr64");
   } else if (part && large && rows <= 128 && wide_modes() && nm % 32 == 0) {
-    hipLaunchKernelGGL((k_tridiag_part<8, 16>), dim3(nm / 32), dim3(512), 8 * 8192, c.stream, a);
-    note_launch(c, "k_tridiag_part<8,16>");
+    TRI_PART(8, 16, 32, "8,16");
   } else if (part && large && rows <= 256 && wide_modes() && nm % 16 == 0) {
-    hipLaunchKernelGGL((k_tridiag_part<8, 32>), dim3(nm / 16), dim3(512), 8 * 8192, c.stream, a);
-    note_launch(c, "k_tridiag_part<8,32>");
+    TRI_PART(8, 32, 16, "8,32");
   } else if (part && large && rows <= 256) {
-    hipLaunchKernelGGL((k_tridiag_part<4, 64>), dim3(nm / 8), dim3(512), 4 * 8192, c.stream, a);
-    note_launch(c, "k_tridiag_part<4>");
+    TRI_PART(4, 64, 8, "4");
   } else if (part && large && rows <= 512) {
-    hipLaunchKernelGGL((k_tridiag_part<8, 64>), dim3(nm / 8), dim3(512), 8 * 8192, c.stream, a);
-    note_launch(c, "k_tridiag_part<8>");
+    TRI_PART(8, 64, 8, "8");
   } else {
     hipLaunchKernelGGL(k_tridiag, dim3((nm + EKPNP_TRI_THREADS - 1) / EKPNP_TRI_THREADS), dim3(EKPNP_TRI_THREADS), 0, c.stream, a);
     note_launch(c, "k_tridiag");
   }
 }
+
+#undef TRI_PART
 
 void launch_phi_efield(Ctx& c) {
   PArgs a = c.pargs();

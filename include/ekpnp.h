@@ -93,7 +93,11 @@ typedef struct ekpnp_ctx ekpnp_ctx;
 int ekpnp_default_params(ekpnp_params* p, int nx, int ny, int nz);
 
 /* Replaces main.cu:58-152 (device selection, the 13+11+3 cudaMallocs, the cuFFT
- * plan and the wavenumber tables) for a whole lattice on the current device. */
+ * plan and the wavenumber tables) for a whole lattice on the current device.
+ * Memory: a lattice whose populations fill less than ~45 % of the device's free memory is timed on up to
+ * EKPNP_PLACEMENT_TRIES (default 5, 1 = off) placements and the fastest is kept - creation then transiently
+ * holds TWO population arenas (more while they fit into 85 % of the free memory).  Processes that share a
+ * device should set EKPNP_PLACEMENT_TRIES=1. */
 int ekpnp_create(const ekpnp_params* p, ekpnp_ctx** out);
 
 /* z-slab variant (no reference counterpart): rank `rank` of `nranks` owns planes
@@ -114,12 +118,17 @@ const char* ekpnp_last_error(const ekpnp_ctx* ctx);
 /* Use the caller's HIP stream (a hipStream_t passed as void*) for all device
  * work of this context instead of the context's own stream. */
 int ekpnp_set_stream(ekpnp_ctx* ctx, void* hip_stream);
+/* Wait for everything enqueued on the context's stream; also brings Ex, Ey, Ez and phi's plates up to date
+ * if a lazy solve left them behind (see ekpnp_fast_poisson). */
 int ekpnp_synchronize(ekpnp_ctx* ctx);
 
 /* Back macroscopic field `field_id` by caller-owned device memory (nz_local*ny*nx
  * doubles, reference layout) instead of the context's own allocation: this is how
  * main.cu's rho_gpu ... T_gpu (main.cu:96-106) stay the arrays it copies out. */
 int ekpnp_bind_field(ekpnp_ctx* ctx, int field_id, double* device_ptr);
+/* The device address of a field array.  Asking for phi, Ex, Ey or Ez (or binding one) makes the context EAGER
+ * from then on: whoever holds the pointer may read or write the array between any two calls, so every solve
+ * writes all four and the collide reads the arrays, as the reference does (see ekpnp_fast_poisson). */
 int ekpnp_field_device_ptr(ekpnp_ctx* ctx, int field_id, double** device_ptr);
 
 /* Host <-> device transfer of one macroscopic field of this context's planes
@@ -150,7 +159,15 @@ int ekpnp_init_equilibrium(ekpnp_ctx* ctx);
 int ekpnp_stream_collide_save(ekpnp_ctx* ctx, double t);
 
 /* void fast_Poisson(charge, chargen, kx, ky, kz, plan) — LBM.h:176, poisson.cu:75-103,
- * including its efield() tail (poisson.cu:28-69): phi, Ex, Ey, Ez from c, cn. */
+ * including its efield() tail (poisson.cu:28-69): phi, Ex, Ey, Ez from c, cn.
+ * Lazy E (round 4): while phi, Ex, Ey, Ez are all the library's own arrays and no device pointer to them has
+ * been handed out, the solve leaves phi's interior planes in the phi array and does NOT write Ex, Ey, Ez or
+ * re-pin phi's plates; the next ekpnp_stream_collide_save forms E = 0.5*(phi(-1) - phi(+1))/d itself - the
+ * expression of gpu_efield / gpu_bc (poisson.cu:40-69), hence the same bits - and the arrays are written the
+ * moment somebody looks (ekpnp_get_field, ekpnp_synchronize, writers, diagnostics, ekpnp_init_equilibrium,
+ * checkpoints).  ekpnp_set_field of any of the four is honoured as in the reference (the collide reads E,
+ * whatever wrote it, LBM.cu:632-637).  EKPNP_LAZY_E=0 or ekpnp_tune(ctx, "lazy_efield", 0): every solve
+ * writes the arrays (rounds 1-3); results are bit-identical either way. */
 int ekpnp_fast_poisson(ekpnp_ctx* ctx);
 /* The collide writes the Poisson right-hand side -F(c - cn)/eps from its registers, and
  * ekpnp_fast_poisson uses it instead of re-reading c, cn when nothing has changed them since:
@@ -245,7 +262,10 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
  * 0 = always separate launches (what large lattices, in-place contexts and slabs do anyway); same
  * results bit for bit.  "tri_partition": the z solve of a single context - 0 = the serial Thomas sweeps
  * everywhere, 1 (default) = the partition solve (spectrum read once) on large lattices of 67 to 514 planes,
- * 2 = wherever it applies; the two solve the same system in a different elimination order (equal to rounding). */
+ * 2 = wherever it applies; the two solve the same system in a different elimination order (equal to rounding).
+ * "tri_pipe": 1 (default) = the partition solves run pipelined (one resident workgroup per compute unit that requests
+ * its next mode group before it solves the current one), 0 = one workgroup per mode group (rounds 2-3); same bits.
+ * "lazy_efield": see ekpnp_fast_poisson; same bits. */
 int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value);
 /* Every kernel launch of the library is checked: a rejected launch makes the entry point return
  * EKPNP_ERR_HIP with the KERNEL's name in ekpnp_last_error.  With EKPNP_DEBUG_SYNC set in the
@@ -261,8 +281,13 @@ int ekpnp_graph_state(const ekpnp_ctx* ctx);
  * for each active lattice; gpu_stream's z wrap (LBM.cu:1972,1975) closes the ring.
  * which: 0 = send-down, 1 = send-up, 2 = recv-from-below, 3 = recv-from-above.   */
 int ekpnp_halo_buffer(ekpnp_ctx* ctx, int which, double** device_ptr, size_t* n_doubles);
+/* Since round 4 neither call copies anything by default: ekpnp_collide_boundary_planes stores the outgoing directions
+ * straight into the send buffers (ekpnp_halo_pack then has nothing left to do), and after ekpnp_halo_unpack - which now
+ * only says "the receive buffers hold the current halos" - the NEXT ekpnp_collide_boundary_planes pulls straight out of
+ * them.  The call sequence is unchanged; the receive buffers must stay untouched between ekpnp_halo_unpack and the next
+ * ekpnp_collide_boundary_planes.  EKPNP_HALO_DIRECT=0 at creation restores the copies through the ghost planes. */
 int ekpnp_halo_pack(ekpnp_ctx* ctx);    /* post-collision boundary planes -> send buffers */
-int ekpnp_halo_unpack(ekpnp_ctx* ctx);  /* recv buffers -> ghost planes                   */
+int ekpnp_halo_unpack(ekpnp_ctx* ctx);  /* recv buffers -> (what the next pull of the edge planes reads) */
 /* One phi plane each way for Ez (poisson.cu:50-55); same `which` numbering. */
 int ekpnp_phi_halo_buffer(ekpnp_ctx* ctx, int which, double** device_ptr, size_t* n_doubles);
 /* Distributed z-tridiagonal (replaces the z part of the 3-D cuFFT, poisson.cu:86-92):

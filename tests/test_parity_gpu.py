@@ -777,6 +777,35 @@ def test_partition_z_solve_vs_oracle(pkg, O, shape, kernel):
     _assert_all(res, name=f"partition_z_solve_vs_oracle_{shape[0]}x{shape[2]}")
 
 
+@pytest.mark.parametrize("shape,kernel", [((128, 64, 300), "k_tridiag_pipe<8>: 576 mode groups on 256 resident workgroups (2.25 turns each)"),
+                                          ((256, 128, 100), "k_tridiag_pipe<8,16>: 544 groups of 32 modes"), ((128, 64, 200), "k_tridiag_pipe<8,32>"),
+                                          ((24, 6, 300), "k_tridiag_pipe<8>: fewer groups than compute units"), ((64, 64, 514), "k_tridiag_pipe<8>, all 64 lanes full")])
+def test_pipelined_z_solve_is_bitwise_the_one_shot_kernel(pkg, O, shape, kernel):
+    """Round 4: the partition z solve runs PIPELINED by default - one resident workgroup per compute unit walks over the
+    mode groups, requests the rows of its next group before it solves the current one and keeps two LDS images
+    (k_tridiag_pipe / k_slab_pipe).  Same arithmetic on the same data in the same order as the one-shot kernels
+    (ekpnp_tune "tri_pipe" 0), which the tests above compare with the oracle: phi and E must come out bit for bit the
+    same - also after several solves in a row (the images alternate) and when a workgroup takes 1, 2 or 3 groups."""
+    rng = np.random.default_rng(17)
+    p = pkg.default_params(*shape)
+    outs = []
+    for pipe in (1, 0):
+        rng = np.random.default_rng(17)
+        with pkg.Solver(p) as s:
+            s.tune("tri_partition", 2)
+            s.tune("tri_pipe", pipe)
+            got = []
+            for _ in range(3):
+                s.set_field("c", 0.01 * (1 + 0.5 * rng.random(shape[::-1])))
+                s.set_field("cn", 0.01 * (1 + 0.5 * rng.random(shape[::-1])))
+                s.fast_Poisson()
+                got.append({k: s.get_field(k) for k in ("phi", "Ez", "Ex")})
+            outs.append(got)
+    for a, b in zip(*outs):
+        for k in a:
+            assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]), (kernel, k, float(np.abs(a[k] - b[k]).max()))
+
+
 @pytest.mark.parametrize("dz", [1.0e-11, 1.0e-5])
 def test_partition_z_solve_extreme_anisotropy_vs_oracle(pkg, O, dz):
     """The same extremes against the ORACLE (its 3-D DFT of the odd extension, the reference's algorithm, poisson.cu:75-204),
@@ -866,13 +895,15 @@ print("REPORT", json.dumps(rep))
             assert np.isfinite(outs[0][k]).all() and np.array_equal(outs[0][k], outs[1][k]), (in_place, k)
 
 
-@pytest.mark.parametrize("shape", [(1024, 1024, 10), (512, 512, 12)])
+@pytest.mark.parametrize("shape", [(1024, 1024, 10), (512, 512, 12), (512, 1024, 10), (1024, 512, 10)])
 def test_own_plane_transforms_equal_rocfft(pkg, O, monkeypatch, shape):
     """Planes of 1024 x 1024 (cfg5) are transformed by the library's own row and column kernels (csrc/fft_plane.h: 2 + 2
     kernels per solve, rocFFT needs 4 + 4 there); EKPNP_OWN_FFT=0 at creation keeps the rocFFT plans.  The two must give
     the same Poisson solve to rounding: random concentrations, one context (k_tridiag_pcr64 / serial z solve) and two
     slabs (the distributed solve), phi and E.  The own path against the ORACLE at this width:
     tests/test_group_gpu.py::test_interior_rank_at_cfg5_width_vs_oracle."""
+    # (ADVICE r03: the MIXED planes too - 512 x 1024 takes the own passes by default (its columns are 1024 long): the 256-point
+    # row pass, the 1024-row column pass and the second twiddle table at fft_tw + nx; 1024 x 512 only with EKPNP_OWN_FFT=1)
     # (512 x 512 planes take rocFFT by default - its 2 + 2 kernels are as fast there - and the own passes, the 256-point
     # row transform and the 512-point column transform, only with EKPNP_OWN_FFT=1: exercised here all the same)
     rng = np.random.default_rng(3)

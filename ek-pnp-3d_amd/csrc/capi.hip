@@ -105,8 +105,8 @@ extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
   if (std::strcmp(knob, "ab_zchunk") == 0 && value >= 0) { c.ab_zchunk = value; return EKPNP_OK; }
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
-  if (std::strcmp(knob, "tri_pipe") == 0 && (value == 0 || value == 1)) {  // the A/B partner of the pipelined z solves
-    c.tri_pipe = value != 0 && c.tri_lds_ok && tridiag_pipe_prepare_device();
+  if (std::strcmp(knob, "tri_pipe") == 0 && (value == 0 || value == 1)) {  // the A/B partner of the one-shot partition z solves
+    c.tri_pipe = (value != 0 && c.tri_lds_ok && tridiag_pipe_prepare_device()) ? 1 : 0;
     drop_graph(c);
     return EKPNP_OK;
   }
@@ -324,7 +324,8 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   if (hipDeviceGetAttribute(&c.ncus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || c.ncus < 1) { (void)hipGetLastError(); c.ncus = 256; }
   {
     const char* e = std::getenv("EKPNP_TRI_PIPE");
-    c.tri_pipe = c.tri_lds_ok && (!e || std::atoi(e) != 0) && tridiag_pipe_prepare_device();
+    const int want = e ? std::atoi(e) : 0;  // default: the one-shot kernels (the pipelined form measured slower, poisson.hip)
+    c.tri_pipe = (c.tri_lds_ok && want > 0 && tridiag_pipe_prepare_device()) ? 1 : 0;
   }
   if (const char* e = std::getenv("EKPNP_BULK_ZCHUNK")) c.ab_zchunk = std::atoi(e) > 0 ? std::atoi(e) : 0;
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;

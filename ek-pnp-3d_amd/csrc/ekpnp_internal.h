@@ -262,7 +262,8 @@ struct Ctx {
   double2* fft_tw = nullptr;       // their twiddle table exp(-2 pi i k / 1024)
   hipfftHandle plan_fwd = 0, plan_inv = 0;
   bool tri_lds_ok = false;  // this context's device grants the partition z solves their dynamic LDS (tridiag_prepare_device)
-  bool tri_pipe = false;    // the partition z solves run pipelined (resident workgroups that prefetch the next mode group; EKPNP_TRI_PIPE, ekpnp_tune "tri_pipe")
+  int tri_pipe = 0;         // partition z solves: 0 (default) one workgroup per mode group, 1 the pipelined form (A/B partner: measured slower)
+  // (resident workgroups that prefetch the next mode group; EKPNP_TRI_PIPE, ekpnp_tune "tri_pipe")
   int ncus = 0;             // compute units of the context's device (the grid of the pipelined z solves)
   int tri_partition = 1;  // z solve of a single context: 0 serial sweeps, 1 partition solve on large lattices, 2 wherever it applies
   bool have_fwd = false, have_inv = false;  // each handle is destroyed on its own (a failing second plan must not leak the first)

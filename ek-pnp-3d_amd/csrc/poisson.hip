@@ -265,8 +265,8 @@ struct TriPart {
   static constexpr int IMAGE = LANES * R * MC;  // double2 elements of one LDS image [LANES R slots][MC columns] = R x 8 KB
 
   // the workgroup's rows of mode group m0 .. m0 + MC - 1, coalesced (thread (c, t): rows t + TR r of column c), into registers
-  static __device__ __forceinline__ void load(const double2* __restrict__ rows, long long ms, long long m0, int n, double2 (&v)[R]) {
-    const int c = threadIdx.x % MC, t = threadIdx.x / MC;
+  static __device__ __forceinline__ void load(const double2* __restrict__ rows, long long ms, long long m0, int n, double2 (&v)[R], const int tid = threadIdx.x) {
+    const int c = tid % MC, t = tid / MC;
     const double2* src = rows + m0 + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -276,8 +276,8 @@ struct TriPart {
     }
   }
   // registers -> LDS image (the rows change owner there)
-  static __device__ __forceinline__ void put(double2* __restrict__ img, const double2 (&v)[R]) {
-    const int c = threadIdx.x % MC, t = threadIdx.x / MC;
+  static __device__ __forceinline__ void put(double2* __restrict__ img, const double2 (&v)[R], const int tid = threadIdx.x) {
+    const int c = tid % MC, t = tid / MC;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s = t + TR * r;
@@ -285,8 +285,8 @@ struct TriPart {
     }
   }
   // LDS image -> global, the way the rows came
-  static __device__ __forceinline__ void store(double2* __restrict__ rows, long long ms, long long m0, int n, const double2* __restrict__ img) {
-    const int c = threadIdx.x % MC, t = threadIdx.x / MC;
+  static __device__ __forceinline__ void store(double2* __restrict__ rows, long long ms, long long m0, int n, const double2* __restrict__ img, const int tid = threadIdx.x) {
+    const int c = tid % MC, t = tid / MC;
     double2* dst = rows + m0 + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -411,15 +411,24 @@ __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __res
   TP::store(rows, ms, m0, n, tp_lds);
 }
 
-// Pipelined form (round 4).  Counters of the one-shot kernel on cfg3 (profiles/r04_cfg3_pmc_sq_lds_tcc.json, k_tridiag_part<8,64>):
-// the waves are PARKED at a waitcnt or a barrier for 66 % of their cycles and issue instructions for 13.5 % (VALU 8.1 %, LDS
-// 4.3 %; LDS bank conflicts 4 % of the LDS cycles): neither arithmetic nor LDS bounds it - each workgroup loads, THEN computes,
-// THEN stores, and two workgroups per CU (64 KB of LDS each) do not interleave those phases: 2.2 GB in 0.55 ms = 4.0 TB/s.
-// Here ONE workgroup per CU stays resident and walks over the mode groups g = blockIdx.x, + gridDim.x, ...: the rows of
-// group g + gridDim.x are requested (into registers) BEFORE group g is solved and land during the solve, the solution of
-// group g is stored while the next iteration runs, and two LDS images (2 x 64 KB) take turns so that one barrier pair per
-// group suffices.  Plain global loads survive __syncthreads() (a bare s_barrier when no LDS-DMA is in flight).
-// Same arithmetic on the same data in the same order as the one-shot kernel: bit-identical results.
+// Pipelined form (round 4) - an experiment that LOST and is kept only as the A/B partner (EKPNP_TRI_PIPE=1, ekpnp_tune
+// "tri_pipe"); the default stays the one-shot kernel above.
+// Counters of the one-shot kernel on cfg3 (profiles/r04_cfg3_pmc_sq_lds_tcc.json, k_tridiag_part<8,64>): its waves are PARKED
+// at a waitcnt or a barrier for 66 % of their cycles and issue for 13.5 % (VALU 8.1 %, LDS 4.3 %; bank conflicts 4 % of the
+// LDS cycles; L2 hit rate 0.63 = second halves of lines): neither arithmetic nor LDS throughput bounds it.  The reading that
+// the load / solve / store PHASES of the two workgroups per CU fail to overlap suggested keeping one workgroup per CU
+// resident: it walks over the mode groups g = blockIdx.x, + gridDim.x, ..., requests the rows of its next group (into
+// registers) BEFORE it solves the current one, and alternates between two LDS images.  Measured (tools/ab_tri_pipe.sh,
+// profiles/r04_ab_tri_pipe_kernel_times.log, rocprofv3, 33 solves): 512 planes 516 us one-shot / 536 us pipelined,
+// 258 planes 219 / 227, 130 planes 89 / 104 - and a wave-specialised variant (8 solver waves + 8 or 4 mover waves per
+// resident workgroup, removed again) 825 / 753 us.  What that says: the SOLVE is the long pole, not the memory phases - a
+// chain of dependent long-latency operations per mode (7 eliminations with a reciprocal each, then six reduction levels of
+// ten cross-lane exchanges through the LDS crossbar + two reciprocals), ~7 us per group at the two waves per SIMD one
+// workgroup has; the one-shot shape runs TWO groups' chains side by side (4 waves per SIMD) and additionally overlaps one
+// group's loads with the other's solve, which is why it wins.  The levers left are inside the solve (fewer reduction levels
+// per byte: more rows per lane - registers -; DPP instead of ds_bpermute for the short strides), worth <= 0.1 ms of a 41 ms step.
+// Same arithmetic on the same data in the same order as the one-shot kernel: bit-identical results
+// (tests/test_parity_gpu.py::test_pipelined_z_solve_is_bitwise_the_one_shot_kernel).
 template <int R, int LANES, bool SLAB>
 __device__ __forceinline__ void tridiag_pipe_body(const PArgs& a, double2* __restrict__ rows, const int n, const double* __restrict__ bound, const int ngroups) {
   using TP = TriPart<R, LANES>;
@@ -457,7 +466,7 @@ __global__ void __launch_bounds__(512) k_slab_part(PArgs a, int row_a, int m, co
   tridiag_part_body<R, LANES, true>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound);
 }
 
-// the pipelined forms: one resident workgroup per CU (two waves per SIMD: the register file is theirs), 2 x R x 8 KB of LDS
+// the pipelined forms (A/B partner, see tridiag_pipe_body): one resident workgroup per CU, 2 x R x 8 KB of LDS
 template <int R, int LANES = 64>
 __global__ void __launch_bounds__(512, 2) k_tridiag_pipe(PArgs a, int ngroups) {
   tridiag_pipe_body<R, LANES, false>(a, a.spec + (long long)a.ny * a.nxh, a.nz - 2, nullptr, ngroups);
@@ -1088,7 +1097,7 @@ void launch_slab_reduce_correct(Ctx& c) {
     // one-shot kernel (a workgroup per mode group) or, c.tri_pipe, the pipelined form (resident workgroups that prefetch)
 #define SLAB_PART(RR, LL, GROUP, NAME)                                                                                           \
     do {                                                                                                                         \
-      if (c.tri_pipe) {                                                                                                          \
+      if (c.tri_pipe) {                                                                                                   \
         const int ng = nm / (GROUP);                                                                                             \
         hipLaunchKernelGGL((k_slab_pipe<RR, LL>), dim3(ng < c.ncus ? ng : c.ncus), dim3(512), 2 * (RR) * 8192, c.stream, a, c.slab_row_a, m, c.edge_local, ng); \
         note_launch(c, "k_slab_pipe<" NAME ">");                                                                                 \
@@ -1164,7 +1173,7 @@ bool tridiag_pipe_prepare_device() {
 // one-shot kernel (a workgroup per mode group) or, c.tri_pipe, the pipelined form (resident workgroups that prefetch)
 #define TRI_PART(RR, LL, GROUP, NAME)                                                                                            \
     do {                                                                                                                         \
-      if (c.tri_pipe) {                                                                                                          \
+      if (c.tri_pipe) {                                                                                                   \
         const int ng = nm / (GROUP);                                                                                             \
         hipLaunchKernelGGL((k_tridiag_pipe<RR, LL>), dim3(ng < c.ncus ? ng : c.ncus), dim3(512), 2 * (RR) * 8192, c.stream, a, ng); \
         note_launch(c, "k_tridiag_pipe<" NAME ">");                                                                              \

@@ -263,8 +263,9 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
  * results bit for bit.  "tri_partition": the z solve of a single context - 0 = the serial Thomas sweeps
  * everywhere, 1 (default) = the partition solve (spectrum read once) on large lattices of 67 to 514 planes,
  * 2 = wherever it applies; the two solve the same system in a different elimination order (equal to rounding).
- * "tri_pipe": 1 (default) = the partition solves run pipelined (one resident workgroup per compute unit that requests
- * its next mode group before it solves the current one), 0 = one workgroup per mode group (rounds 2-3); same bits.
+ * "tri_pipe": 0 (default) = one workgroup per mode group, 1 = the partition solves run pipelined (one resident workgroup
+ * per compute unit that requests its next mode group before it solves the current one; measured 4-16 % slower, kept as
+ * the A/B partner); same bits.
  * "lazy_efield": see ekpnp_fast_poisson; same bits. */
 int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value);
 /* Every kernel launch of the library is checked: a rejected launch makes the entry point return

@@ -781,11 +781,12 @@ def test_partition_z_solve_vs_oracle(pkg, O, shape, kernel):
                                           ((256, 128, 100), "k_tridiag_pipe<8,16>: 544 groups of 32 modes"), ((128, 64, 200), "k_tridiag_pipe<8,32>"),
                                           ((24, 6, 300), "k_tridiag_pipe<8>: fewer groups than compute units"), ((64, 64, 514), "k_tridiag_pipe<8>, all 64 lanes full")])
 def test_pipelined_z_solve_is_bitwise_the_one_shot_kernel(pkg, O, shape, kernel):
-    """Round 4: the partition z solve runs PIPELINED by default - one resident workgroup per compute unit walks over the
-    mode groups, requests the rows of its next group before it solves the current one and keeps two LDS images
-    (k_tridiag_pipe / k_slab_pipe).  Same arithmetic on the same data in the same order as the one-shot kernels
-    (ekpnp_tune "tri_pipe" 0), which the tests above compare with the oracle: phi and E must come out bit for bit the
-    same - also after several solves in a row (the images alternate) and when a workgroup takes 1, 2 or 3 groups."""
+    """Round 4 experiment, kept as an A/B partner (ekpnp_tune "tri_pipe" 1; it measured slower, poisson.hip): the partition z
+    solve PIPELINED - one resident workgroup per compute unit walks over the mode groups, requests the rows of its next
+    group before it solves the current one and keeps two LDS images (k_tridiag_pipe / k_slab_pipe).  Same arithmetic on
+    the same data in the same order as the one-shot kernels (the default), which the tests above compare with the
+    oracle: phi and E must come out bit for bit the same - also after several solves in a row (the images alternate) and
+    when a workgroup takes 1, 2 or 3 groups."""
     rng = np.random.default_rng(17)
     p = pkg.default_params(*shape)
     outs = []

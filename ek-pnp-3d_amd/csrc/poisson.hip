@@ -21,17 +21,20 @@
 namespace ekpnp {
 
 // ---- the 2-D transforms of the interior planes ---------------------------------------------------------------------
-// rocFFT plans (hipFFT API) everywhere except on planes of 1024 x 1024 (cfg5), where rocFFT has no strided-column kernel
-// and transposes instead (4 + 4 kernels, 3.2 ms per solve on a 1024 x 1024 x 128 slab); there the library's own row and
-// column passes run (fft_plane.h: 0.84 + 0.81 ms).  EKPNP_OWN_FFT=0 at creation keeps rocFFT (the A/B partner).
+// The library's own row and column passes (fft_plane.h) on planes of 512 / 1024 x 512 / 1024 nodes - cfg3, cfg4, cfg5 -,
+// rocFFT plans (hipFFT API) everywhere else.  On 1024-long columns rocFFT has no strided-column kernel and transposes
+// (4 + 4 kernels, 3.2 ms per solve on a 1024 x 1024 x 128 slab against 0.84 + 0.81 ms); on 512-long ones its 2 + 2 kernels
+// are nearly as fast (1.66 against 1.60 ms per solve on cfg3).  EKPNP_OWN_FFT=0 at creation keeps rocFFT (the A/B partner).
 int plane_fft_setup(Ctx& c) {
   c.own_fft = false;
   const char* e = std::getenv("EKPNP_OWN_FFT");
-  // default: the own passes where rocFFT transposes (1024-long columns); EKPNP_OWN_FFT=1 also on 512-long ones, =0 never
+  // default: the own passes wherever they exist (rows of 512 or 1024 nodes, columns of 512 or 1024); EKPNP_OWN_FFT=0: never.
+  // Rounds 2-3 kept rocFFT on 512-long columns (kernel against kernel the own passes gain only 0.06 ms per solve there);
+  // inside the full cfg3 step the Poisson phase is 2.12 ms with them against 2.25 ms with rocFFT's plans - the z solve
+  // between the passes runs faster too (490 vs 514 us) - and the plans' work areas go (profiles/r04_ab_own_fft_512.log).
   const int want = e ? std::atoi(e) : -1;
   if (want == 0) return EKPNP_OK;
   if (!fft_x_supported(c.p.nx) || !fft_y_supported(c.p.ny, c.nxh)) return EKPNP_OK;
-  if (want < 0 && c.p.ny != 1024) return EKPNP_OK;
   if (!fft_x_prepare(c.p.nx) || !fft_y_prepare(c.p.ny)) return EKPNP_OK;  // this device does not grant the LDS: rocFFT
   // one table serves both passes when the plane is square: exp(-2 pi i k / NX), then exp(-2 pi i k / NY)
   std::vector<double2> h((size_t)c.p.nx + c.p.ny);

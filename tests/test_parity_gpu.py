@@ -898,15 +898,14 @@ print("REPORT", json.dumps(rep))
 
 @pytest.mark.parametrize("shape", [(1024, 1024, 10), (512, 512, 12), (512, 1024, 10), (1024, 512, 10)])
 def test_own_plane_transforms_equal_rocfft(pkg, O, monkeypatch, shape):
-    """Planes of 1024 x 1024 (cfg5) are transformed by the library's own row and column kernels (csrc/fft_plane.h: 2 + 2
-    kernels per solve, rocFFT needs 4 + 4 there); EKPNP_OWN_FFT=0 at creation keeps the rocFFT plans.  The two must give
-    the same Poisson solve to rounding: random concentrations, one context (k_tridiag_pcr64 / serial z solve) and two
-    slabs (the distributed solve), phi and E.  The own path against the ORACLE at this width:
-    tests/test_group_gpu.py::test_interior_rank_at_cfg5_width_vs_oracle."""
-    # (ADVICE r03: the MIXED planes too - 512 x 1024 takes the own passes by default (its columns are 1024 long): the 256-point
-    # row pass, the 1024-row column pass and the second twiddle table at fft_tw + nx; 1024 x 512 only with EKPNP_OWN_FFT=1)
-    # (512 x 512 planes take rocFFT by default - its 2 + 2 kernels are as fast there - and the own passes, the 256-point
-    # row transform and the 512-point column transform, only with EKPNP_OWN_FFT=1: exercised here all the same)
+    """Planes of 512 / 1024 x 512 / 1024 nodes (cfg3, cfg4, cfg5) are transformed by the library's own row and column kernels
+    (csrc/fft_plane.h: 2 + 2 kernels per solve; rocFFT needs 4 + 4 on 1024-long columns and is 0.13 ms per solve slower
+    inside the cfg3 step); EKPNP_OWN_FFT=0 at creation keeps the rocFFT plans.  The two must give the same Poisson solve to
+    rounding: random concentrations, one context (k_tridiag_pcr64 / serial z solve) and two slabs (the distributed solve),
+    phi and E - square planes of both sizes and the two MIXED ones: the 256-point row pass with the 1024-row
+    column pass and the second twiddle table at fft_tw + nx, and vice versa.  The own path against the ORACLE:
+    tests/test_group_gpu.py::test_interior_rank_at_cfg5_width_vs_oracle (1024 wide), test_full_size_vs_oracle[cfg3_width]
+    (512 wide, since round 4 the default there too)."""
     rng = np.random.default_rng(3)
     p = pkg.default_params(*shape)
     cc, cn = 0.01 * (1 + 0.5 * rng.random(shape[::-1])), 0.01 * (1 + 0.5 * rng.random(shape[::-1]))

@@ -42,7 +42,8 @@ for k in sorted(set(pf) | set(pw)):
                          "hbm_read_bytes": f * 1024 * fetch_factor, "hbm_write_bytes": w * 1024 * write_factor,
                          "hbm_bytes_per_launch": f * 1024 * fetch_factor + w * 1024 * write_factor}
 json.dump(out, open(os.path.join(dst, f"{tag}_{wl}_pmc_summary.json"), "w"), indent=1)
-bulk = next(k for k in out["kernels"] if "k_collide_bulk" in k and "true" in k)
+# the steady-state sweep is the PULL = true instantiation (first template flag; the second, since round 4, says whether E is formed from phi)
+bulk = next(k for k in out["kernels"] if "k_collide_bulk<" in k and k.split("k_collide_bulk<", 1)[1].split(",")[1].strip() == "true")
 tpath = os.path.join(dst, "pmc_traffic.json")
 t = json.load(open(tpath)) if os.path.exists(tpath) else {}
 t[wl] = {"kernel": bulk, "hbm_bytes_per_launch": out["kernels"][bulk]["hbm_bytes_per_launch"], "round": tag,

@@ -536,6 +536,10 @@ def main():
         # ranks sharing one device must not race for its free memory: the placement search of ekpnp_create holds up to two
         # extra population arenas for a moment, and a rank that loses that race would leave its peers in ncclCommInitRank
         os.environ.setdefault("EKPNP_PLACEMENT_TRIES", "1")
+        # ... and keep rocFFT's plans: with the library's own plane transforms (workgroups of 36 - 66 KB of LDS) four processes
+        # time-sliced on ONE device ran 1.6 s per step against 48 ms (profiles/r04_rehearsal_4ranks_knobs.log) - a property of
+        # sharing a device between processes, not of the transforms (one process per device: 0.13 ms per solve FASTER)
+        os.environ.setdefault("EKPNP_OWN_FFT", "0")
     torch.cuda.set_device(local_rank)
     pkg = G.load_package()
 

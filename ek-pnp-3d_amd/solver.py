@@ -436,7 +436,7 @@ class Solver:
         self._ck(self._L.ekpnp_load_checkpoint(self._h, os.fsencode(path), C.byref(t)))
         return t.value
 
-    # -- z-slab pieces (driven by slab.py) ---------------------------------------------------
+    # -- z-slab pieces: the split entry points (a host's own transport, examples/host_transport.py; tests) ------
     def call(self, name: str):
         """Invoke a parameterless `int ekpnp_<name>(ctx)` entry point."""
         self._ck(getattr(self._L, "ekpnp_" + name)(self._h))

@@ -863,7 +863,7 @@ def test_partition_z_solve_extreme_anisotropy(pkg, O, dz):
 
 
 def test_placement_search_changes_no_bit(pkg, O, tmp_path):
-    """ekpnp_create times the real sweep on up to three population arenas and keeps the fastest (capi.hip placement_search).
+    """ekpnp_create times the real sweep on several population arenas (default up to 5; here EKPNP_PLACEMENT_TRIES=3) and keeps the fastest (capi.hip placement_search).
     Which arena is kept must not change a single bit of the results, and the probe sweeps must leave no trace (they run on
     an all-zero lattice and write NaN moments): the same run with EKPNP_PLACEMENT_TRIES=1 (no search) in another process
     gives identical fields.  512 x 128 x 80: 5.2 M nodes, above the 4 M-node threshold of the search."""

@@ -105,6 +105,8 @@ extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
   if (std::strcmp(knob, "ab_zchunk") == 0 && value >= 0) { c.ab_zchunk = value; return EKPNP_OK; }
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
+  if (std::strcmp(knob, "tri_wide") == 0 && (value == 0 || value == 1)) { c.tri_wide = value != 0 && c.tri_lds_ok && tridiag_wide_prepare_device(); drop_graph(c); return EKPNP_OK; }
+  if (std::strcmp(knob, "tri_opt") == 0 && value >= 0 && value <= 3) { c.tri_opt = value; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_pipe") == 0 && (value == 0 || value == 1)) {  // the A/B partner of the one-shot partition z solves
     c.tri_pipe = (value != 0 && c.tri_lds_ok && tridiag_pipe_prepare_device()) ? 1 : 0;
     drop_graph(c);
@@ -248,6 +250,7 @@ PArgs Ctx::pargs() const {
   a.dx = p.dx; a.dy = p.dy; a.dz = p.dz;
   a.Lx = p.Lx; a.Ly = p.Ly;
   a.inv_nxny = 1.0 / ((double)p.nx * (double)p.ny);
+  a.tri_opt = tri_opt;
   return a;
 }
 
@@ -331,6 +334,11 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
   if (const char* e = std::getenv("EKPNP_LAZY_E")) c.lazy_efield = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("EKPNP_HALO_DIRECT")) c.halo_direct = std::atoi(e) != 0;
+  if (const char* e = std::getenv("EKPNP_TRI_OPT")) c.tri_opt = std::atoi(e) & 3;
+  {
+    const char* e = std::getenv("EKPNP_TRI_WIDE");
+    c.tri_wide = c.tri_lds_ok && (e ? std::atoi(e) != 0 : false) && tridiag_wide_prepare_device();
+  }
   if (const char* e = std::getenv("EKPNP_TRI_PARTITION")) c.tri_partition = std::atoi(e) < 0 ? 0 : (std::atoi(e) > 2 ? 2 : std::atoi(e));
   // In-place mode: one buffer per lattice with `shift` spare planes.  A sweep writes plane z of
   // the new state `shift` planes below (parity 0, bulk launches of `zchunk` planes in ascending z)

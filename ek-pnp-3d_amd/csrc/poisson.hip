@@ -258,12 +258,12 @@ __device__ __forceinline__ double recip(double x) {
 // 4 (5) levels and serves all of them at once, and a workgroup covers 32 (16) adjacent modes: 512 (256) contiguous
 // bytes per row.
 // ---- the pieces of the partition solve (shared by the one-shot kernels and the pipelined ones below) ---------------------
-template <int R, int LANES>
+template <int R, int LANES, int NW = 8>
 struct TriPart {
   static constexpr int MPW = 64 / LANES;        // modes per wavefront
-  static constexpr int MC = 8 * MPW;            // modes (LDS columns) per workgroup of 8 wavefronts
+  static constexpr int MC = NW * MPW;           // modes (LDS columns) per workgroup of NW wavefronts (8; 16: twice as wide pieces of every row)
   static_assert(LANES * R <= 512 && 64 % LANES == 0, "a column has LANES x R row slots");
-  static constexpr int TR = 512 / MC;           // rows loaded per pass of the workgroup
+  static constexpr int TR = 64 * NW / MC;       // rows loaded per pass of the workgroup
   static constexpr int FM = (MC < 16 ? MC : 16) - 1;  // the column index is XOR-ed with the owning lane (mod 16 columns = 256 bytes of banks)
   static constexpr int IMAGE = LANES * R * MC;  // double2 elements of one LDS image [LANES R slots][MC columns] = R x 8 KB
 
@@ -301,9 +301,9 @@ struct TriPart {
 
 // the solve proper, on an LDS image: every lane takes its R rows out of the image, eliminates, takes part in the cyclic
 // reduction of the interface rows and puts its R solution rows back
-template <int R, int LANES, bool SLAB>
+template <int R, int LANES, bool SLAB, int NW = 8>
 __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __restrict__ img, const long long m0, const int n, const double* __restrict__ bound) {
-  using TP = TriPart<R, LANES>;
+  using TP = TriPart<R, LANES, NW>;
   constexpr int MPW = TP::MPW, MC = TP::MC, FM = TP::FM;
   const long long ms = (long long)a.ny * a.nxh;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -329,6 +329,28 @@ __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __re
   // interior rows k = 0 .. R-2 of this lane
   double cp[R - 1], v[R - 1], wv[R - 1];
   {
+    // A/B knob of round 4 (a.tri_opt bit 1, default OFF: it changed nothing measurable, profiles/r04_ab_tri_opt.log).  The
+    // pivots 1/(B_k - A_k c'_{k-1}) do not depend on the data, and their recurrence is a CHAIN of R-1 reciprocals (a
+    // quarter-rate instruction + two Newton steps each, every one waiting for the one before); with the knob they come
+    // from the determinant recurrence  q_k = B_k q_{k-1} - A_k C_{k-1} q_{k-2},  1/pivot_k = q_{k-1} / q_k  -
+    // a chain of R-1 fused multiply-adds - followed by R-1 INDEPENDENT reciprocals.  |q_k| <= (|b| + 1)^k stays far inside
+    // the double range for R <= 8 (|b| ~ 1e7 at dz/dx = 1e3: 1e49).  Equal to the chained form to rounding.
+    double pinv[R - 1];
+    if (a.tri_opt & 2) {
+      double qm2 = 1.0, qm1 = 1.0, cm1 = 0.0;  // q_{k-2}, q_{k-1}, C_{k-1} (coupling of row k-1 to row k as the elimination sees it)
+#pragma unroll
+      for (int k = 0; k < R - 1; ++k) {
+        const int s = R * l + k;
+        const bool real = s < n;
+        const double Ain = (real && k > 0) ? 1.0 : 0.0;
+        const double Bk = real ? b : 1.0;
+        const double q = fma(Bk, qm1, -(Ain * cm1) * qm2);
+        pinv[k] = qm1 * recip(q);
+        qm2 = qm1;
+        qm1 = q;
+        cm1 = (k < R - 2 && real && s < n - 1) ? 1.0 : 0.0;
+      }
+    }
     double cprev = 0.0, vprev = 0.0;
     double2 gprev = make_double2(0.0, 0.0);
 #pragma unroll
@@ -339,7 +361,7 @@ __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __re
       const double A0 = (real && k == 0 && s > 0) ? 1.0 : 0.0;      // coupling of the first row to y[l-1]
       const double Bk = real ? b : 1.0;
       const double Cany = (real && s < n - 1) ? 1.0 : 0.0;          // coupling to the row after
-      const double inv = recip(Bk - Ain * cprev);
+      const double inv = (a.tri_opt & 2) ? pinv[k] : recip(Bk - Ain * cprev);
       cp[k] = (k < R - 2 ? Cany : 0.0) * inv;
       g[k] = make_double2((g[k].x - Ain * gprev.x) * inv, (g[k].y - Ain * gprev.y) * inv);
       v[k] = (A0 - Ain * vprev) * inv;
@@ -371,8 +393,19 @@ __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __re
     if (l == LANES - 1) up = 0.0;
     if (l == 0) lo = 0.0;
   }
+  // Parallel cyclic reduction of the interface rows.  (A/B knob of round 4, a.tri_opt bit 0, default OFF - it changed
+  // nothing measurable, profiles/r04_ab_tri_opt.log, so the reduction keeps all its levels and rounds 2-3's bits:)
+  // After j levels the couplings lo, up of a mode have fallen to ~mu^(2^j) of the diagonal (mu ~ lambda^R, lambda the small root of lambda^2 + b lambda + 1 = 0): once they are below
+  // 2^-66 of it in EVERY lane of the wavefront, a further level changes bd, rr, ri by less than 2^-66 max|rr| - an absolute
+  // bound like k_slab_edges', ~1e-20 of the field's scale, invisible after the inverse transform mixes all modes - and the
+  // reduction stops (round 4, a.tri_opt bit 0; the couplings depend on b and the lane only, so the vote is about the
+  // modes, not the data).  The lowest modes (b -> -2) take all log2(LANES) levels, most take 2 - 3.
 #pragma unroll
   for (int st = 1; st < LANES; st <<= 1) {
+    if (a.tri_opt & 1) {
+      const double tiny = 1.3552527156068805e-20 * fabs(bd);  // 2^-66
+      if (__all(fabs(lo) <= tiny && fabs(up) <= tiny)) break;
+    }
     double lo_l = __shfl_up(lo, st, LANES), up_l = __shfl_up(up, st, LANES), bd_l = __shfl_up(bd, st, LANES);
     double rr_l = __shfl_up(rr, st, LANES), ri_l = __shfl_up(ri, st, LANES);
     double lo_u = __shfl_down(lo, st, LANES), up_u = __shfl_down(up, st, LANES), bd_u = __shfl_down(bd, st, LANES);
@@ -397,10 +430,10 @@ __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __re
   mine[(R - 1) * MC] = make_double2(yx * a.inv_nxny, yy * a.inv_nxny);
 }
 
-template <int R, int LANES, bool SLAB>
+template <int R, int LANES, bool SLAB, int NW = 8>
 __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __restrict__ rows, const int n, const double* __restrict__ bound) {
-  using TP = TriPart<R, LANES>;
-  extern __shared__ double2 tp_lds[];    // [LANES R slots][MC columns] = R x 8 KB
+  using TP = TriPart<R, LANES, NW>;
+  extern __shared__ double2 tp_lds[];    // [LANES R slots][MC columns] = R x NW KB
   const long long ms = (long long)a.ny * a.nxh;
   const long long m0 = (long long)blockIdx.x * TP::MC;
   {
@@ -409,13 +442,13 @@ __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __res
     TP::put(tp_lds, v);
   }
   __syncthreads();
-  tridiag_part_solve<R, LANES, SLAB>(a, tp_lds, m0, n, bound);
+  tridiag_part_solve<R, LANES, SLAB, NW>(a, tp_lds, m0, n, bound);
   __syncthreads();
   TP::store(rows, ms, m0, n, tp_lds);
 }
 
 // Pipelined form (round 4) - an experiment that LOST and is kept only as the A/B partner (EKPNP_TRI_PIPE=1, ekpnp_tune
-// "tri_pipe"); the default stays the one-shot kernel above.
+// "tri_pipe"); the default stays the one-shot kernel above.  (Summary of ALL the round's z-solve experiments: DESIGN.md §4.)
 // Counters of the one-shot kernel on cfg3 (profiles/r04_cfg3_pmc_sq_lds_tcc.json, k_tridiag_part<8,64>): its waves are PARKED
 // at a waitcnt or a barrier for 66 % of their cycles and issue for 13.5 % (VALU 8.1 %, LDS 4.3 %; bank conflicts 4 % of the
 // LDS cycles; L2 hit rate 0.63 = second halves of lines): neither arithmetic nor LDS throughput bounds it.  The reading that
@@ -424,12 +457,15 @@ __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __res
 // registers) BEFORE it solves the current one, and alternates between two LDS images.  Measured (tools/ab_tri_pipe.sh,
 // profiles/r04_ab_tri_pipe_kernel_times.log, rocprofv3, 33 solves): 512 planes 516 us one-shot / 536 us pipelined,
 // 258 planes 219 / 227, 130 planes 89 / 104 - and a wave-specialised variant (8 solver waves + 8 or 4 mover waves per
-// resident workgroup, removed again) 825 / 753 us.  What that says: the SOLVE is the long pole, not the memory phases - a
-// chain of dependent long-latency operations per mode (7 eliminations with a reciprocal each, then six reduction levels of
-// ten cross-lane exchanges through the LDS crossbar + two reciprocals), ~7 us per group at the two waves per SIMD one
-// workgroup has; the one-shot shape runs TWO groups' chains side by side (4 waves per SIMD) and additionally overlaps one
-// group's loads with the other's solve, which is why it wins.  The levers left are inside the solve (fewer reduction levels
-// per byte: more rows per lane - registers -; DPP instead of ds_bpermute for the short strides), worth <= 0.1 ms of a 41 ms step.
+// resident workgroup, removed again) 825 / 753 us.  Hiding the memory phases does not help.  Nor does shortening the solve:
+// stopping the cyclic reduction once the couplings are below 2^-66 (2 - 3 levels instead of 6 for most modes) and taking the
+// pivots without the reciprocal chain (a.tri_opt) leave the kernel at 500 - 507 us (profiles/r04_ab_tri_opt.log).  Sixteen
+// wavefronts = 16 modes per workgroup (256-byte pieces of every row, EKPNP_TRI_WIDE=1): 500 against 516 us.  What all shapes
+// share is the ACCESS PATTERN - 510 pieces of 128 (256) bytes, 2.1 MB apart, read and later written per workgroup -, and a
+// plain copy with that pattern takes 0.51 ms too (round 2's probe): the kernel runs at the speed the memory system gives
+// this pattern, ~4.4 TB/s.  A spectrum with z as the fastest index inside blocks of 8 planes would make a mode's rows
+// contiguous (and the LDS image unnecessary), but the four transform passes would have to produce and consume it: sized at
+// 0.14 ms of a 41 ms step, not built.
 // Same arithmetic on the same data in the same order as the one-shot kernel: bit-identical results
 // (tests/test_parity_gpu.py::test_pipelined_z_solve_is_bitwise_the_one_shot_kernel).
 template <int R, int LANES, bool SLAB>
@@ -458,15 +494,15 @@ __device__ __forceinline__ void tridiag_pipe_body(const PArgs& a, double2* __res
   }
 }
 
-template <int R, int LANES = 64>
-__global__ void __launch_bounds__(512) k_tridiag_part(PArgs a) {
-  tridiag_part_body<R, LANES, false>(a, a.spec + (long long)a.ny * a.nxh, a.nz - 2, nullptr);
+template <int R, int LANES = 64, int NW = 8>
+__global__ void __launch_bounds__(64 * NW) k_tridiag_part(PArgs a) {
+  tridiag_part_body<R, LANES, false, NW>(a, a.spec + (long long)a.ny * a.nxh, a.nz - 2, nullptr);
 }
 
 // z slab: the same solve on the slab's m unknown rows (first one on local plane row_a), spectrum read once
-template <int R, int LANES = 64>
-__global__ void __launch_bounds__(512) k_slab_part(PArgs a, int row_a, int m, const double* __restrict__ bound) {
-  tridiag_part_body<R, LANES, true>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound);
+template <int R, int LANES = 64, int NW = 8>
+__global__ void __launch_bounds__(64 * NW) k_slab_part(PArgs a, int row_a, int m, const double* __restrict__ bound) {
+  tridiag_part_body<R, LANES, true, NW>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound);
 }
 
 // the pipelined forms (A/B partner, see tridiag_pipe_body): one resident workgroup per CU, 2 x R x 8 KB of LDS
@@ -1114,7 +1150,10 @@ void launch_slab_reduce_correct(Ctx& c) {
     else if (m <= 128) SLAB_PART(2, 64, 8, "2");
     else if (m <= 256 && wide_modes() && nm % 16 == 0) SLAB_PART(8, 32, 16, "8,32");
     else if (m <= 256) SLAB_PART(4, 64, 8, "4");
-    else SLAB_PART(8, 64, 8, "8");
+    else if (c.tri_wide && nm % 16 == 0) {
+      hipLaunchKernelGGL((k_slab_part<8, 64, 16>), dim3(nm / 16), dim3(1024), 16 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
+      note_launch(c, "k_slab_part<8,64,16>");
+    } else SLAB_PART(8, 64, 8, "8");
 #undef SLAB_PART
     return;
   }
@@ -1150,6 +1189,13 @@ bool tridiag_prepare_device() {
   lds(reinterpret_cast<const void*>(&k_slab_part<2, 64>), 2 * 8192);
   lds(reinterpret_cast<const void*>(&k_slab_part<8, 32>), 8 * 8192);
   lds(reinterpret_cast<const void*>(&k_slab_part<8, 16>), 8 * 8192);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
+}
+// the 16-wavefront forms (128 KB of LDS): a device that does not grant it keeps the 8-wavefront kernels
+bool tridiag_wide_prepare_device() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_part<8, 64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_part<8, 64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192);
   if (e != hipSuccess) { (void)hipGetLastError(); return false; }
   return true;
 }
@@ -1203,6 +1249,10 @@ void launch_tridiag(Ctx& c) {
     TRI_PART(8, 32, 16, "8,32");
   } else if (part && large && rows <= 256) {
     TRI_PART(4, 64, 8, "4");
+  } else if (part && large && rows <= 512 && c.tri_wide && nm % 16 == 0) {
+    // 16 wavefronts = 16 adjacent modes per workgroup: every row is read and written in 256-byte pieces instead of 128-byte ones
+    hipLaunchKernelGGL((k_tridiag_part<8, 64, 16>), dim3(nm / 16), dim3(1024), 16 * 8192, c.stream, a);
+    note_launch(c, "k_tridiag_part<8,64,16>");
   } else if (part && large && rows <= 512) {
     TRI_PART(8, 64, 8, "8");
   } else {

@@ -807,6 +807,33 @@ def test_pipelined_z_solve_is_bitwise_the_one_shot_kernel(pkg, O, shape, kernel)
             assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]), (kernel, k, float(np.abs(a[k] - b[k]).max()))
 
 
+def test_z_solve_ab_knobs_of_round_4(pkg, O):
+    """The other A/B partners of DESIGN.md section 4's table, all default OFF: 16 modes per workgroup (tri_wide: same
+    arithmetic per mode, bit-identical) and the shortened solve (tri_opt: the cyclic reduction stops once the couplings are
+    below 2^-66 of the diagonal, the pivots come from the determinant recurrence - equal to rounding: 1e-13 of phi on a
+    400-plane channel, and with ALL the charge in the two planes next to one plate, where a dropped coupling term meets
+    the largest right-hand sides, relative to max |phi|)."""
+    shape = (128, 64, 400)
+    p = pkg.default_params(*shape)
+    rng = np.random.default_rng(29)
+    cases = [(0.01 * (1 + 0.5 * rng.random(shape[::-1])), 0.01 * (1 + 0.5 * rng.random(shape[::-1])))]
+    cc = np.full(shape[::-1], 0.01)
+    cc[1:3] *= 1.0 + 50.0 * rng.random(cc[1:3].shape)
+    cases.append((cc, np.full(shape[::-1], 0.01)))
+    for cc, cn in cases:
+        res = {}
+        for name, knob, val in (("base", "tri_opt", 0), ("wide", "tri_wide", 1), ("opt", "tri_opt", 3)):
+            with pkg.Solver(p) as s:
+                s.tune("tri_partition", 2)
+                s.tune(knob, val)
+                s.set_field("c", cc); s.set_field("cn", cn)
+                s.fast_Poisson()
+                res[name] = s.get_field("phi")
+        assert np.array_equal(res["wide"], res["base"])
+        err = np.abs(res["opt"] - res["base"]).max() / np.abs(res["base"]).max()
+        assert err < 1e-13, err
+
+
 @pytest.mark.parametrize("dz", [1.0e-11, 1.0e-5])
 def test_partition_z_solve_extreme_anisotropy_vs_oracle(pkg, O, dz):
     """The same extremes against the ORACLE (its 3-D DFT of the odd extension, the reference's algorithm, poisson.cu:75-204),

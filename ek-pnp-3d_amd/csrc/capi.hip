@@ -1263,10 +1263,15 @@ extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
       hi.B[l] = c.stage[l] + (ptrdiff_t)c.pplane - (ptrdiff_t)c.nzl * (ptrdiff_t)c.pplane;  // plane zg = nzl -> staging plane 1
     }
   }
-  launch_collide_walls(c, lo, c.stream, true, false);
-  launch_collide_walls(c, hi, c.stream, false, true);
-  if (c.z0 != 0) { if (c.halo_direct) launch_collide_bulk_edge(c, lo, 0); else launch_collide_bulk(c, lo, 0, 1); }
-  if (c.z0 + c.nzl != c.p.nz) { if (c.halo_direct) launch_collide_bulk_edge(c, hi, c.nzl - 1); else launch_collide_bulk(c, hi, c.nzl - 1, c.nzl); }
+  static const bool merged_faces = !(std::getenv("EKPNP_MERGED_FACES") && std::atoi(std::getenv("EKPNP_MERGED_FACES")) == 0);  // A/B knob
+  if (c.halo_direct && merged_faces) {
+    launch_collide_faces(c, lo, hi);  // both faces, plate or not, in one launch
+  } else {
+    launch_collide_walls(c, lo, c.stream, true, false);
+    launch_collide_walls(c, hi, c.stream, false, true);
+    if (c.z0 != 0) { if (c.halo_direct) launch_collide_bulk_edge(c, lo, 0); else launch_collide_bulk(c, lo, 0, 1); }
+    if (c.z0 + c.nzl != c.p.nz) { if (c.halo_direct) launch_collide_bulk_edge(c, hi, c.nzl - 1); else launch_collide_bulk(c, hi, c.nzl - 1, c.nzl); }
+  }
   c.halo_sent = c.halo_direct;
   c.halo_recv_valid = false;  // consumed; the exchange that follows refills the buffers, ekpnp_halo_unpack says when
   c.collide_phase = 1;

@@ -150,6 +150,7 @@ void launch_init_equilibrium(Ctx&);
 void launch_collide_all(Ctx&);  // launch-bound lattices: plates and bulk in ONE launch (single two-buffer context)
 void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
 void launch_collide_bulk(Ctx&, const KArgs&, int zl_begin, int zl_end);
+void launch_collide_faces(Ctx&, const KArgs& lo, const KArgs& hi);  // a slab's first and last plane (plate or interior face each) in ONE launch
 void launch_collide_bulk_edge(Ctx&, const KArgs&, int zl);  // one slab edge plane: KArgs::halo_* honoured (EDGE kernels)
 void launch_collide_walls(Ctx&, const KArgs&, hipStream_t stream, bool lower, bool upper);
 void launch_halo_pack_stage(Ctx&);

@@ -547,6 +547,28 @@ __global__ void __launch_bounds__(64 * NL) k_collide_wall(const KArgs a, const i
   wall_body<NL, PULL, EPHI>(a, first_wall + (int)blockIdx.z, (int)(blockIdx.x * 64 + (threadIdx.x & 63)), (int)blockIdx.y);
 }
 
+// Both faces of a slab in ONE launch (round 4): rows [0, ny) are the slab's first plane, rows [ny, 2 ny) its last one; each is
+// a plate (wall_body) or an interior face (the bulk body with EDGE), decided per face - uniform over a workgroup, like the
+// row.  The two faces may differ in where their new populations go (in-place slabs stage them) and in their halo buffers:
+// two argument blocks, selected by the row.  Replaces up to two plate launches and two edge launches per step; the bodies
+// are the ones of k_collide_wall / k_collide_edge, so every node gets the same bits.
+template <int NL, bool PULL, bool EPHI>
+__global__ void __launch_bounds__(64 * NL) k_collide_faces(const KArgs lo, const KArgs hi, const int lo_plate, const int hi_plate, const int nxb, const int rchunk) {
+  int xb;
+  const int ny = lo.ny;
+  const int row = bulk_row_of_block(2 * ny, nxb, rchunk, xb);
+  if (row < 0) return;
+  // (the argument block is chosen by BRANCHING, not by a pointer: taking the address of a by-value kernel argument sends
+  // the whole block through scratch memory - 1 KB per lane in the first build of this kernel)
+  if (row < ny) {
+    if (lo_plate) wall_body<NL, PULL, EPHI>(lo, 0, xb * 64 + (int)(threadIdx.x & 63), row);
+    else bulk_body<NL, PULL, EPHI, true>(lo, 0, row, xb);
+  } else {
+    if (hi_plate) wall_body<NL, PULL, EPHI>(hi, 1, xb * 64 + (int)(threadIdx.x & 63), row - ny);
+    else bulk_body<NL, PULL, EPHI, true>(hi, hi.nzl - 1, row - ny, xb);
+  }
+}
+
 // Launch-bound lattices (the reference's own 50x8x51: wall planes 12 us, bulk 10 us, both pure latency):
 // ONE launch for the whole lattice.  The rows beyond the bulk rows are the plates' rows (the row, hence the branch, is
 // uniform over the workgroup, so every barrier is reached by whole workgroups).
@@ -775,6 +797,32 @@ static void edge_dispatch(Ctx& c, const KArgs& a, int zl) {
     else hipLaunchKernelGGL((k_collide_edge<NL, true, false>), g, b, 0, c.stream, a, zl, nrows, nxb, rchunk);
   }
   note_launch(c, "k_collide_edge");
+}
+
+template <int NL>
+static void faces_dispatch(Ctx& c, const KArgs& lo, const KArgs& hi, int lo_plate, int hi_plate) {
+  const int nrows = 2 * c.p.ny, nxb = (c.p.nx + 63) / 64, rchunk = 64;
+  const long long per_xcd = ((long long)nrows + 8LL * rchunk - 1) / (8LL * rchunk) * rchunk;
+  dim3 g((unsigned)(8 * per_xcd * nxb)), b(64 * NL);
+  const bool ephi = collide_takes_e_from_phi(c);
+  if (c.streamed_state) {
+    if (ephi) hipLaunchKernelGGL((k_collide_faces<NL, false, (NL > 1)>), g, b, 0, c.stream, lo, hi, lo_plate, hi_plate, nxb, rchunk);
+    else hipLaunchKernelGGL((k_collide_faces<NL, false, false>), g, b, 0, c.stream, lo, hi, lo_plate, hi_plate, nxb, rchunk);
+  } else {
+    if (ephi) hipLaunchKernelGGL((k_collide_faces<NL, true, (NL > 1)>), g, b, 0, c.stream, lo, hi, lo_plate, hi_plate, nxb, rchunk);
+    else hipLaunchKernelGGL((k_collide_faces<NL, true, false>), g, b, 0, c.stream, lo, hi, lo_plate, hi_plate, nxb, rchunk);
+  }
+  note_launch(c, "k_collide_faces");
+}
+
+// a slab's first and last plane in one launch (plates and / or interior faces; KArgs::halo_* honoured)
+void launch_collide_faces(Ctx& c, const KArgs& lo, const KArgs& hi) {
+  const int lo_plate = c.z0 == 0, hi_plate = c.z0 + c.nzl == c.p.nz;
+  switch (c.p.n_lattices) {
+    case 1: faces_dispatch<1>(c, lo, hi, lo_plate, hi_plate); break;
+    case 3: faces_dispatch<3>(c, lo, hi, lo_plate, hi_plate); break;
+    default: faces_dispatch<4>(c, lo, hi, lo_plate, hi_plate); break;
+  }
 }
 
 void launch_collide_bulk_edge(Ctx& c, const KArgs& a, int zl) {

@@ -630,3 +630,20 @@ def test_slab_edge_values_with_charge_at_one_plate(pkg):
         for k in one:
             err = np.abs(four[k] - one[k]).max() / np.abs(one[k]).max()
             assert err < 1e-12, (at_top, k, err)
+
+
+def test_cpp_driver_ends_cleanly_when_one_slab_fails(tmp_path):
+    """`ekpnp_main --devices 0,0,0` (one process, three slabs, no control plane) with the fault-injection knob rejecting a
+    launch on slab 1 in the middle of the run: the program must END - non-zero, with the slab and the kernel named - rather
+    than hang on the slabs that went ahead (round 4: a failing group verb drains every stream and poisons the group;
+    `fail()` of csrc/ekpnp_main.cpp then destroys it)."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ek-pnp-3d_amd", "ekpnp_main")
+    if not os.path.exists(exe):
+        pytest.skip("ekpnp_main not built")
+    env = dict(os.environ, EKPNP_INJECT_LAUNCH_FAILURE="k_collide_bulk@1#7")
+    r = subprocess.run([exe, "--nx", "24", "--ny", "6", "--nz", "36", "--steps", "40", "--nsave", "15", "--print-current", "10",
+                        "--out", str(tmp_path), "--devices", "0,0,0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    assert "slab 1" in r.stderr and "kernel k_collide_bulk" in r.stderr, r.stderr[-2000:]

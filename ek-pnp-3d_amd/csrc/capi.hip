@@ -106,12 +106,6 @@ extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_wide") == 0 && (value == 0 || value == 1)) { c.tri_wide = value != 0 && c.tri_lds_ok && tridiag_wide_prepare_device(); drop_graph(c); return EKPNP_OK; }
-  if (std::strcmp(knob, "tri_opt") == 0 && value >= 0 && value <= 3) { c.tri_opt = value; drop_graph(c); return EKPNP_OK; }
-  if (std::strcmp(knob, "tri_pipe") == 0 && (value == 0 || value == 1)) {  // the A/B partner of the one-shot partition z solves
-    c.tri_pipe = (value != 0 && c.tri_lds_ok && tridiag_pipe_prepare_device()) ? 1 : 0;
-    drop_graph(c);
-    return EKPNP_OK;
-  }
   if (std::strcmp(knob, "lazy_efield") == 0 && (value == 0 || value == 1)) {  // the A/B partner of the EPHI kernels: 0 = k_phi_efield in every solve
     const int rc = ensure_efield(c);
     c.lazy_efield = value;
@@ -250,7 +244,6 @@ PArgs Ctx::pargs() const {
   a.dx = p.dx; a.dy = p.dy; a.dz = p.dz;
   a.Lx = p.Lx; a.Ly = p.Ly;
   a.inv_nxny = 1.0 / ((double)p.nx * (double)p.ny);
-  a.tri_opt = tri_opt;
   return a;
 }
 
@@ -325,16 +318,10 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   if (hipGetDevice(&c.device) != hipSuccess) { c.err = "hipGetDevice failed"; return bail(EKPNP_ERR_HIP); }
   c.tri_lds_ok = tridiag_prepare_device();
   if (hipDeviceGetAttribute(&c.ncus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || c.ncus < 1) { (void)hipGetLastError(); c.ncus = 256; }
-  {
-    const char* e = std::getenv("EKPNP_TRI_PIPE");
-    const int want = e ? std::atoi(e) : 0;  // default: the one-shot kernels (the pipelined form measured slower, poisson.hip)
-    c.tri_pipe = (c.tri_lds_ok && want > 0 && tridiag_pipe_prepare_device()) ? 1 : 0;
-  }
   if (const char* e = std::getenv("EKPNP_BULK_ZCHUNK")) c.ab_zchunk = std::atoi(e) > 0 ? std::atoi(e) : 0;
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
   if (const char* e = std::getenv("EKPNP_LAZY_E")) c.lazy_efield = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("EKPNP_HALO_DIRECT")) c.halo_direct = std::atoi(e) != 0;
-  if (const char* e = std::getenv("EKPNP_TRI_OPT")) c.tri_opt = std::atoi(e) & 3;
   {
     const char* e = std::getenv("EKPNP_TRI_WIDE");
     c.tri_wide = c.tri_lds_ok && (e ? std::atoi(e) != 0 : false) && tridiag_wide_prepare_device();

@@ -136,7 +136,6 @@ struct PArgs {
   long long plane;
   double F, eps, voltage, voltage2, dx, dy, dz, inv_nxny, Lx, Ly;
   double rhs_wall_lo, rhs_wall_hi;  // as in KArgs
-  int tri_opt;                      // partition z solves: bit 0 early exit of the cyclic reduction, bit 1 pivots from the determinant recurrence
 };
 
 struct Ctx;
@@ -167,7 +166,6 @@ int plane_fft_forward(Ctx&);    // fft_in() -> fft_spec(): the own kernels or th
 int plane_fft_inverse(Ctx&);    // fft_spec() -> fft_out()
 void launch_tridiag(Ctx&);
 bool tridiag_prepare_device();  // per-device function attributes of the partition z solves (current device)
-bool tridiag_pipe_prepare_device();  // ... of their pipelined forms (2 LDS images)
 bool tridiag_wide_prepare_device();  // ... of the 16-wavefront forms (128 KB of LDS)
 void launch_phi_efield(Ctx&);
 void launch_slab_thomas_local(Ctx&);
@@ -266,9 +264,6 @@ struct Ctx {
   hipfftHandle plan_fwd = 0, plan_inv = 0;
   bool tri_lds_ok = false;  // this context's device grants the partition z solves their dynamic LDS (tridiag_prepare_device)
   bool tri_wide = false;    // columns of more than 256 rows: 16 modes (wavefronts) per workgroup = 256-byte pieces of every row (EKPNP_TRI_WIDE, ekpnp_tune "tri_wide")
-  int tri_opt = 0;          // partition z solves, A/B knobs of round 4 that changed nothing measurable (default 0 = rounds 2-3's arithmetic): bit 0 the cyclic reduction stops when the couplings are below 2^-66, bit 1 chain-free pivots (EKPNP_TRI_OPT, ekpnp_tune "tri_opt")
-  int tri_pipe = 0;         // partition z solves: 0 (default) one workgroup per mode group, 1 the pipelined form (A/B partner: measured slower)
-  // (resident workgroups that prefetch the next mode group; EKPNP_TRI_PIPE, ekpnp_tune "tri_pipe")
   int ncus = 0;             // compute units of the context's device (the grid of the pipelined z solves)
   int tri_partition = 1;  // z solve of a single context: 0 serial sweeps, 1 partition solve on large lattices, 2 wherever it applies
   bool have_fwd = false, have_inv = false;  // each handle is destroyed on its own (a failing second plan must not leak the first)

@@ -329,28 +329,6 @@ __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __re
   // interior rows k = 0 .. R-2 of this lane
   double cp[R - 1], v[R - 1], wv[R - 1];
   {
-    // A/B knob of round 4 (a.tri_opt bit 1, default OFF: it changed nothing measurable, profiles/r04_ab_tri_opt.log).  The
-    // pivots 1/(B_k - A_k c'_{k-1}) do not depend on the data, and their recurrence is a CHAIN of R-1 reciprocals (a
-    // quarter-rate instruction + two Newton steps each, every one waiting for the one before); with the knob they come
-    // from the determinant recurrence  q_k = B_k q_{k-1} - A_k C_{k-1} q_{k-2},  1/pivot_k = q_{k-1} / q_k  -
-    // a chain of R-1 fused multiply-adds - followed by R-1 INDEPENDENT reciprocals.  |q_k| <= (|b| + 1)^k stays far inside
-    // the double range for R <= 8 (|b| ~ 1e7 at dz/dx = 1e3: 1e49).  Equal to the chained form to rounding.
-    double pinv[R - 1];
-    if (a.tri_opt & 2) {
-      double qm2 = 1.0, qm1 = 1.0, cm1 = 0.0;  // q_{k-2}, q_{k-1}, C_{k-1} (coupling of row k-1 to row k as the elimination sees it)
-#pragma unroll
-      for (int k = 0; k < R - 1; ++k) {
-        const int s = R * l + k;
-        const bool real = s < n;
-        const double Ain = (real && k > 0) ? 1.0 : 0.0;
-        const double Bk = real ? b : 1.0;
-        const double q = fma(Bk, qm1, -(Ain * cm1) * qm2);
-        pinv[k] = qm1 * recip(q);
-        qm2 = qm1;
-        qm1 = q;
-        cm1 = (k < R - 2 && real && s < n - 1) ? 1.0 : 0.0;
-      }
-    }
     double cprev = 0.0, vprev = 0.0;
     double2 gprev = make_double2(0.0, 0.0);
 #pragma unroll
@@ -361,7 +339,7 @@ __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __re
       const double A0 = (real && k == 0 && s > 0) ? 1.0 : 0.0;      // coupling of the first row to y[l-1]
       const double Bk = real ? b : 1.0;
       const double Cany = (real && s < n - 1) ? 1.0 : 0.0;          // coupling to the row after
-      const double inv = (a.tri_opt & 2) ? pinv[k] : recip(Bk - Ain * cprev);
+      const double inv = recip(Bk - Ain * cprev);
       cp[k] = (k < R - 2 ? Cany : 0.0) * inv;
       g[k] = make_double2((g[k].x - Ain * gprev.x) * inv, (g[k].y - Ain * gprev.y) * inv);
       v[k] = (A0 - Ain * vprev) * inv;
@@ -393,19 +371,8 @@ __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __re
     if (l == LANES - 1) up = 0.0;
     if (l == 0) lo = 0.0;
   }
-  // Parallel cyclic reduction of the interface rows.  (A/B knob of round 4, a.tri_opt bit 0, default OFF - it changed
-  // nothing measurable, profiles/r04_ab_tri_opt.log, so the reduction keeps all its levels and rounds 2-3's bits:)
-  // After j levels the couplings lo, up of a mode have fallen to ~mu^(2^j) of the diagonal (mu ~ lambda^R, lambda the small root of lambda^2 + b lambda + 1 = 0): once they are below
-  // 2^-66 of it in EVERY lane of the wavefront, a further level changes bd, rr, ri by less than 2^-66 max|rr| - an absolute
-  // bound like k_slab_edges', ~1e-20 of the field's scale, invisible after the inverse transform mixes all modes - and the
-  // reduction stops (round 4, a.tri_opt bit 0; the couplings depend on b and the lane only, so the vote is about the
-  // modes, not the data).  The lowest modes (b -> -2) take all log2(LANES) levels, most take 2 - 3.
 #pragma unroll
   for (int st = 1; st < LANES; st <<= 1) {
-    if (a.tri_opt & 1) {
-      const double tiny = 1.3552527156068805e-20 * fabs(bd);  // 2^-66
-      if (__all(fabs(lo) <= tiny && fabs(up) <= tiny)) break;
-    }
     double lo_l = __shfl_up(lo, st, LANES), up_l = __shfl_up(up, st, LANES), bd_l = __shfl_up(bd, st, LANES);
     double rr_l = __shfl_up(rr, st, LANES), ri_l = __shfl_up(ri, st, LANES);
     double lo_u = __shfl_down(lo, st, LANES), up_u = __shfl_down(up, st, LANES), bd_u = __shfl_down(bd, st, LANES);
@@ -447,53 +414,10 @@ __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __res
   TP::store(rows, ms, m0, n, tp_lds);
 }
 
-// Pipelined form (round 4) - an experiment that LOST and is kept only as the A/B partner (EKPNP_TRI_PIPE=1, ekpnp_tune
-// "tri_pipe"); the default stays the one-shot kernel above.  (Summary of ALL the round's z-solve experiments: DESIGN.md §4.)
-// Counters of the one-shot kernel on cfg3 (profiles/r04_cfg3_pmc_sq_lds_tcc.json, k_tridiag_part<8,64>): its waves are PARKED
-// at a waitcnt or a barrier for 66 % of their cycles and issue for 13.5 % (VALU 8.1 %, LDS 4.3 %; bank conflicts 4 % of the
-// LDS cycles; L2 hit rate 0.63 = second halves of lines): neither arithmetic nor LDS throughput bounds it.  The reading that
-// the load / solve / store PHASES of the two workgroups per CU fail to overlap suggested keeping one workgroup per CU
-// resident: it walks over the mode groups g = blockIdx.x, + gridDim.x, ..., requests the rows of its next group (into
-// registers) BEFORE it solves the current one, and alternates between two LDS images.  Measured (tools/ab_tri_pipe.sh,
-// profiles/r04_ab_tri_pipe_kernel_times.log, rocprofv3, 33 solves): 512 planes 516 us one-shot / 536 us pipelined,
-// 258 planes 219 / 227, 130 planes 89 / 104 - and a wave-specialised variant (8 solver waves + 8 or 4 mover waves per
-// resident workgroup, removed again) 825 / 753 us.  Hiding the memory phases does not help.  Nor does shortening the solve:
-// stopping the cyclic reduction once the couplings are below 2^-66 (2 - 3 levels instead of 6 for most modes) and taking the
-// pivots without the reciprocal chain (a.tri_opt) leave the kernel at 500 - 507 us (profiles/r04_ab_tri_opt.log).  Sixteen
-// wavefronts = 16 modes per workgroup (256-byte pieces of every row, EKPNP_TRI_WIDE=1): 500 against 516 us.  What all shapes
-// share is the ACCESS PATTERN - 510 pieces of 128 (256) bytes, 2.1 MB apart, read and later written per workgroup -, and a
-// plain copy with that pattern takes 0.51 ms too (round 2's probe): the kernel runs at the speed the memory system gives
-// this pattern, ~4.4 TB/s.  A spectrum with z as the fastest index inside blocks of 8 planes would make a mode's rows
-// contiguous (and the LDS image unnecessary), but the four transform passes would have to produce and consume it: sized at
-// 0.14 ms of a 41 ms step, not built.
-// Same arithmetic on the same data in the same order as the one-shot kernel: bit-identical results
-// (tests/test_parity_gpu.py::test_pipelined_z_solve_is_bitwise_the_one_shot_kernel).
-template <int R, int LANES, bool SLAB>
-__device__ __forceinline__ void tridiag_pipe_body(const PArgs& a, double2* __restrict__ rows, const int n, const double* __restrict__ bound, const int ngroups) {
-  using TP = TriPart<R, LANES>;
-  extern __shared__ double2 tp_lds[];    // two images
-  const long long ms = (long long)a.ny * a.nxh;
-  int g = blockIdx.x;
-  if (g >= ngroups) return;              // whole workgroup
-  double2 v[R];
-  TP::load(rows, ms, (long long)g * TP::MC, n, v);
-  int buf = 0;
-  for (; g < ngroups; g += gridDim.x) {
-    double2* img = tp_lds + buf * TP::IMAGE;
-    const long long m0 = (long long)g * TP::MC;
-    TP::put(img, v);
-    const int gn = g + gridDim.x;
-    if (gn < ngroups) TP::load(rows, ms, (long long)gn * TP::MC, n, v);  // in flight during the solve below
-    __syncthreads();
-    tridiag_part_solve<R, LANES, SLAB>(a, img, m0, n, bound);
-    __syncthreads();
-    TP::store(rows, ms, m0, n, img);
-    // the image written next is the OTHER one; this one is written again only after the two barriers of the next
-    // iteration, which every thread passes after its reads here
-    buf ^= 1;
-  }
-}
-
+// What bounds this kernel, with counters, and the five restructurings that were built, measured and removed again in round 4
+// (pipelined with register prefetch, wave-specialised, early-exit reduction, chain-free pivots; 16 modes per workgroup stays
+// as the tri_wide knob): DESIGN.md section 4 - the access pattern (510 pieces of 128 bytes, a plane apart, per workgroup),
+// 4.4 TB/s, which a plain copy of that shape does not beat either.
 template <int R, int LANES = 64, int NW = 8>
 __global__ void __launch_bounds__(64 * NW) k_tridiag_part(PArgs a) {
   tridiag_part_body<R, LANES, false, NW>(a, a.spec + (long long)a.ny * a.nxh, a.nz - 2, nullptr);
@@ -503,16 +427,6 @@ __global__ void __launch_bounds__(64 * NW) k_tridiag_part(PArgs a) {
 template <int R, int LANES = 64, int NW = 8>
 __global__ void __launch_bounds__(64 * NW) k_slab_part(PArgs a, int row_a, int m, const double* __restrict__ bound) {
   tridiag_part_body<R, LANES, true, NW>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound);
-}
-
-// the pipelined forms (A/B partner, see tridiag_pipe_body): one resident workgroup per CU, 2 x R x 8 KB of LDS
-template <int R, int LANES = 64>
-__global__ void __launch_bounds__(512, 2) k_tridiag_pipe(PArgs a, int ngroups) {
-  tridiag_pipe_body<R, LANES, false>(a, a.spec + (long long)a.ny * a.nxh, a.nz - 2, nullptr, ngroups);
-}
-template <int R, int LANES = 64>
-__global__ void __launch_bounds__(512, 2) k_slab_pipe(PArgs a, int row_a, int m, const double* __restrict__ bound, int ngroups) {
-  tridiag_pipe_body<R, LANES, true>(a, a.spec + (long long)row_a * a.ny * a.nxh, m, bound, ngroups);
 }
 
 // Short channels (NZ - 2 <= 64 unknown rows, e.g. the reference's own 51 planes): the serial
@@ -1133,17 +1047,11 @@ void launch_slab_reduce_correct(Ctx& c) {
   note_launch(c, "k_slab_interface");
   if (slab_read_once(c)) {
     const int m = c.slab_m;
-    // one-shot kernel (a workgroup per mode group) or, c.tri_pipe, the pipelined form (resident workgroups that prefetch)
+    // (launch + name of one instantiation)
 #define SLAB_PART(RR, LL, GROUP, NAME)                                                                                           \
     do {                                                                                                                         \
-      if (c.tri_pipe) {                                                                                                   \
-        const int ng = nm / (GROUP);                                                                                             \
-        hipLaunchKernelGGL((k_slab_pipe<RR, LL>), dim3(ng < c.ncus ? ng : c.ncus), dim3(512), 2 * (RR) * 8192, c.stream, a, c.slab_row_a, m, c.edge_local, ng); \
-        note_launch(c, "k_slab_pipe<" NAME ">");                                                                                 \
-      } else {                                                                                                                   \
         hipLaunchKernelGGL((k_slab_part<RR, LL>), dim3(nm / (GROUP)), dim3(512), (RR) * 8192, c.stream, a, c.slab_row_a, m, c.edge_local); \
         note_launch(c, "k_slab_part<" NAME ">");                                                                                 \
-      }                                                                                                                          \
     } while (0)
     // short columns: several modes per wavefront (LANES of the partition solve) where the mode count allows whole workgroups
     if (m <= 128 && wide_modes() && nm % 32 == 0) SLAB_PART(8, 16, 32, "8,16");
@@ -1200,36 +1108,11 @@ bool tridiag_wide_prepare_device() {
   return true;
 }
 
-// ... and of the pipelined forms (two LDS images: up to 128 KB of the CU's 160 KB)
-bool tridiag_pipe_prepare_device() {
-  hipError_t e = hipSuccess;
-  auto lds = [&](const void* fn, int bytes) {
-    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  };
-  lds(reinterpret_cast<const void*>(&k_tridiag_pipe<8, 64>), 16 * 8192);
-  lds(reinterpret_cast<const void*>(&k_tridiag_pipe<4, 64>), 8 * 8192);
-  lds(reinterpret_cast<const void*>(&k_tridiag_pipe<8, 32>), 16 * 8192);
-  lds(reinterpret_cast<const void*>(&k_tridiag_pipe<8, 16>), 16 * 8192);
-  lds(reinterpret_cast<const void*>(&k_slab_pipe<8, 64>), 16 * 8192);
-  lds(reinterpret_cast<const void*>(&k_slab_pipe<4, 64>), 8 * 8192);
-  lds(reinterpret_cast<const void*>(&k_slab_pipe<2, 64>), 4 * 8192);
-  lds(reinterpret_cast<const void*>(&k_slab_pipe<8, 32>), 16 * 8192);
-  lds(reinterpret_cast<const void*>(&k_slab_pipe<8, 16>), 16 * 8192);
-  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-  return true;
-}
-
-// one-shot kernel (a workgroup per mode group) or, c.tri_pipe, the pipelined form (resident workgroups that prefetch)
+// launch + name of one instantiation of the partition solve
 #define TRI_PART(RR, LL, GROUP, NAME)                                                                                            \
     do {                                                                                                                         \
-      if (c.tri_pipe) {                                                                                                   \
-        const int ng = nm / (GROUP);                                                                                             \
-        hipLaunchKernelGGL((k_tridiag_pipe<RR, LL>), dim3(ng < c.ncus ? ng : c.ncus), dim3(512), 2 * (RR) * 8192, c.stream, a, ng); \
-        note_launch(c, "k_tridiag_pipe<" NAME ">");                                                                              \
-      } else {                                                                                                                   \
         hipLaunchKernelGGL((k_tridiag_part<RR, LL>), dim3(nm / (GROUP)), dim3(512), (RR) * 8192, c.stream, a);                   \
         note_launch(c, "k_tridiag_part<" NAME ">");                                                                              \
-      }                                                                                                                          \
     } while (0)
 void launch_tridiag(Ctx& c) {
   PArgs a = c.pargs();

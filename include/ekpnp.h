@@ -263,12 +263,8 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
  * results bit for bit.  "tri_partition": the z solve of a single context - 0 = the serial Thomas sweeps
  * everywhere, 1 (default) = the partition solve (spectrum read once) on large lattices of 67 to 514 planes,
  * 2 = wherever it applies; the two solve the same system in a different elimination order (equal to rounding).
- * "tri_pipe": 0 (default) = one workgroup per mode group, 1 = the partition solves run pipelined (one resident workgroup
- * per compute unit that requests its next mode group before it solves the current one; measured 4-16 % slower, kept as
- * the A/B partner); same bits.
- * "tri_wide": 1 = 16 modes per workgroup on columns of more than 256 rows (256-byte pieces, 3 % faster in isolation), same bits;
- * "tri_opt": bit 0 the cyclic reduction stops when the couplings are below 2^-66, bit 1 pivots without the reciprocal chain
- * (equal to rounding; no measurable gain) - both default 0, A/B partners of DESIGN.md section 4's table.
+ * "tri_wide": 1 = 16 modes (wavefronts) per workgroup on columns of more than 256 rows (256-byte pieces of every row; 3 %
+ * faster in isolation, default 0), same bits.
  * "lazy_efield": see ekpnp_fast_poisson; same bits. */
 int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value);
 /* Every kernel launch of the library is checked: a rejected launch makes the entry point return

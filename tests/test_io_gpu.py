@@ -318,13 +318,10 @@ with pkg.Solver(p) as s:
     assert "ERR" in r.stdout and "kernel k_collide_all" in r.stdout, (r.stdout, r.stderr[-2000:])
     r = run({"EKPNP_INJECT_LAUNCH_FAILURE": "k_collide_bulk", "EKPNP_NO_MERGED_WALLS": "1"}, tmp_path / "x.npy")
     assert "ERR" in r.stdout and "kernel k_collide_bulk" in r.stdout, (r.stdout, r.stderr[-2000:])
-    # the z solve has four kernels (and, round 4, the pipelined forms of the partition solves behind EKPNP_TRI_PIPE=1); each launch is noted
-    # under the name of the kernel that was really launched
+    # the z solve has four kernels; each launch is noted under the name of the kernel that was really launched
     for nz, knob, kernel, wide in (("12", "1", "k_tridiag_pcr64", "1"), ("300", "2", "k_tridiag_part<8>", "1"), ("131", "2", "k_tridiag_part<8,32>", "1"),
-                                   ("100", "2", "k_tridiag_part<8,16>", "1"), ("131", "2", "k_tridiag_part<4>", "0"), ("300", "0", "k_tridiag", "1"),
-                                   ("300", "2", "k_tridiag_pipe<8>", "1"), ("100", "2", "k_tridiag_pipe<8,16>", "1")):
-        r = run({"EKPNP_INJECT_LAUNCH_FAILURE": kernel, "EKPNP_TEST_NZ": nz, "EKPNP_TRI_PARTITION": knob, "EKPNP_TRI_WIDE_MODES": wide,
-                 "EKPNP_TRI_PIPE": "1" if "pipe" in kernel else "0"}, tmp_path / "x.npy")
+                                   ("100", "2", "k_tridiag_part<8,16>", "1"), ("131", "2", "k_tridiag_part<4>", "0"), ("300", "0", "k_tridiag", "1")):
+        r = run({"EKPNP_INJECT_LAUNCH_FAILURE": kernel, "EKPNP_TEST_NZ": nz, "EKPNP_TRI_PARTITION": knob, "EKPNP_TRI_WIDE_MODES": wide}, tmp_path / "x.npy")
         assert "ERR" in r.stdout and f"kernel {kernel}:" in r.stdout, (kernel, r.stdout, r.stderr[-2000:])
     a = run({}, tmp_path / "a.npy")
     b = run({"EKPNP_DEBUG_SYNC": "1"}, tmp_path / "b.npy")

@@ -777,42 +777,10 @@ def test_partition_z_solve_vs_oracle(pkg, O, shape, kernel):
     _assert_all(res, name=f"partition_z_solve_vs_oracle_{shape[0]}x{shape[2]}")
 
 
-@pytest.mark.parametrize("shape,kernel", [((128, 64, 300), "k_tridiag_pipe<8>: 576 mode groups on 256 resident workgroups (2.25 turns each)"),
-                                          ((256, 128, 100), "k_tridiag_pipe<8,16>: 544 groups of 32 modes"), ((128, 64, 200), "k_tridiag_pipe<8,32>"),
-                                          ((24, 6, 300), "k_tridiag_pipe<8>: fewer groups than compute units"), ((64, 64, 514), "k_tridiag_pipe<8>, all 64 lanes full")])
-def test_pipelined_z_solve_is_bitwise_the_one_shot_kernel(pkg, O, shape, kernel):
-    """Round 4 experiment, kept as an A/B partner (ekpnp_tune "tri_pipe" 1; it measured slower, poisson.hip): the partition z
-    solve PIPELINED - one resident workgroup per compute unit walks over the mode groups, requests the rows of its next
-    group before it solves the current one and keeps two LDS images (k_tridiag_pipe / k_slab_pipe).  Same arithmetic on
-    the same data in the same order as the one-shot kernels (the default), which the tests above compare with the
-    oracle: phi and E must come out bit for bit the same - also after several solves in a row (the images alternate) and
-    when a workgroup takes 1, 2 or 3 groups."""
-    rng = np.random.default_rng(17)
-    p = pkg.default_params(*shape)
-    outs = []
-    for pipe in (1, 0):
-        rng = np.random.default_rng(17)
-        with pkg.Solver(p) as s:
-            s.tune("tri_partition", 2)
-            s.tune("tri_pipe", pipe)
-            got = []
-            for _ in range(3):
-                s.set_field("c", 0.01 * (1 + 0.5 * rng.random(shape[::-1])))
-                s.set_field("cn", 0.01 * (1 + 0.5 * rng.random(shape[::-1])))
-                s.fast_Poisson()
-                got.append({k: s.get_field(k) for k in ("phi", "Ez", "Ex")})
-            outs.append(got)
-    for a, b in zip(*outs):
-        for k in a:
-            assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]), (kernel, k, float(np.abs(a[k] - b[k]).max()))
-
-
-def test_z_solve_ab_knobs_of_round_4(pkg, O):
-    """The other A/B partners of DESIGN.md section 4's table, all default OFF: 16 modes per workgroup (tri_wide: same
-    arithmetic per mode, bit-identical) and the shortened solve (tri_opt: the cyclic reduction stops once the couplings are
-    below 2^-66 of the diagonal, the pivots come from the determinant recurrence - equal to rounding: 1e-13 of phi on a
-    400-plane channel, and with ALL the charge in the two planes next to one plate, where a dropped coupling term meets
-    the largest right-hand sides, relative to max |phi|)."""
+def test_sixteen_modes_per_workgroup_is_bitwise_the_default_z_solve(pkg, O):
+    """The one A/B partner of DESIGN.md section 4's table that stayed in the library (ekpnp_tune "tri_wide", default off): 16
+    wavefronts = 16 adjacent modes per workgroup on columns of more than 256 rows, 128 KB of LDS.  Same arithmetic per mode:
+    phi must come out bit for bit the same - random charges, and all the charge in the two planes next to one plate."""
     shape = (128, 64, 400)
     p = pkg.default_params(*shape)
     rng = np.random.default_rng(29)
@@ -821,17 +789,15 @@ def test_z_solve_ab_knobs_of_round_4(pkg, O):
     cc[1:3] *= 1.0 + 50.0 * rng.random(cc[1:3].shape)
     cases.append((cc, np.full(shape[::-1], 0.01)))
     for cc, cn in cases:
-        res = {}
-        for name, knob, val in (("base", "tri_opt", 0), ("wide", "tri_wide", 1), ("opt", "tri_opt", 3)):
+        res = []
+        for wide in (0, 1):
             with pkg.Solver(p) as s:
                 s.tune("tri_partition", 2)
-                s.tune(knob, val)
+                s.tune("tri_wide", wide)
                 s.set_field("c", cc); s.set_field("cn", cn)
                 s.fast_Poisson()
-                res[name] = s.get_field("phi")
-        assert np.array_equal(res["wide"], res["base"])
-        err = np.abs(res["opt"] - res["base"]).max() / np.abs(res["base"]).max()
-        assert err < 1e-13, err
+                res.append(s.get_field("phi"))
+        assert np.isfinite(res[0]).all() and np.array_equal(res[0], res[1])
 
 
 @pytest.mark.parametrize("dz", [1.0e-11, 1.0e-5])

@@ -1,7 +1,7 @@
 """How far is a one-rank slab (library transport, ring to itself) from a single context after a few steps?  Max abs / rel
 difference per field, for the knob combinations given as KEY=VAL,... on the command line (each combination a child process,
 because the knobs are read at creation / first use).
-    python tools/slab_vs_single_diff.py [NXxNYxNZ] [steps] "EKPNP_TRI_PIPE=0" "EKPNP_HALO_DIRECT=0,EKPNP_LAZY_E=0" ... """
+    python tools/slab_vs_single_diff.py [NXxNYxNZ] [steps] "EKPNP_LAZY_E=0" "EKPNP_HALO_DIRECT=0,EKPNP_LAZY_E=0" ... """
 import os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

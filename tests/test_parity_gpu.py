@@ -619,13 +619,14 @@ def test_large_lattice_kernels_vs_oracle(pkg, O, shape, nslabs, in_place):
 @pytest.mark.parametrize("case", ["cfg2", "cfg3_width"])
 def test_full_size_vs_oracle(pkg, O, case):
     """Against the oracle itself at BASELINE sizes.  cfg2 at its FULL size (256x256x256, f + h + hn,
-    Ra = 0: 16.8 M nodes) and cfg3's full 512x512 planes, all four lattices, on 130 planes (34 M nodes;
-    the full 512 planes would need 250 GB of host memory for the oracle - the z extent of cfg3 is
-    covered by test_cfg3_maximum_size_translation_invariance): one Poisson solve and two steps from
-    the bench's start state."""
+    Ra = 0: 16.8 M nodes) and cfg3's full 512x512 planes, all four lattices, on 98 planes (25.7 M nodes:
+    the own row / column transforms, k_tridiag_part<8,16>, the lean bulk / plate kernels, the two-nodes-per-lane
+    phi / E kernel on demand; 130 planes until round 3 - the oracle's share of this test is what the suite's time
+    budget pays for; the full 512 planes would need 250 GB of host memory for the oracle, and the z extent of cfg3
+    is covered by test_cfg3_maximum_size_periodic_tiles): one Poisson solve and two steps from the bench's start state."""
     import bench
 
-    shape, nl = ((256, 256, 256), 3) if case == "cfg2" else ((512, 512, 130), 4)
+    shape, nl = ((256, 256, 256), 3) if case == "cfg2" else ((512, 512, 98), 4)
     po = O.default_params(*shape)
     if nl == 3:
         po.Ra = 0.0

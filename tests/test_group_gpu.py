@@ -591,6 +591,9 @@ def test_edge_planes_without_pack_and_unpack_are_bitwise_the_copied_halos(pkg, O
     if nl < 4:
         p.Ra = 0.0
     outs = []
+    # direct halos with both faces in one launch (k_collide_faces, the default) against the copies of rounds 1-3; the
+    # launch-per-face partner of the faces kernel (EKPNP_MERGED_FACES=0, read once per process) runs in the three-rank
+    # case of tests/test_slab_gpu.py::test_native_rccl_ranks_sharing_one_gpu
     for direct in ("1", "0"):
         monkeypatch.setenv("EKPNP_HALO_DIRECT", direct)
         with pkg.Group(p, nslabs, devices=[0] * nslabs) as g:

@@ -185,6 +185,8 @@ def test_native_rccl_ranks_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_p
     np.savez(tmp_path / "start.npz", **st)
     env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_IN_PLACE=str(in_place), EKPNP_SLAB_GRID="x".join(map(str, shape)),
                OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if nprocs == 3:  # the three-rank case takes the A/B partner of k_collide_faces: a launch per face (k_collide_wall, k_collide_edge)
+        env["EKPNP_MERGED_FACES"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nprocs}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rccl_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)

@@ -38,6 +38,11 @@ try:
 except AttributeError:
     _CPUS_AT_START = os.cpu_count() or 1
 
+# dmabuf IPC: RCCL across processes needs it on this pool (hipIpcGetMemHandle fails without it).  Set HERE, before torch
+# (and with it the HSA runtime) is imported, so that ranks started by `python -m torch.distributed.run ... bench.py` - the
+# driver's launch - have it exactly like the ranks bench.py spawns itself (spawn_ranks); an explicit setting wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -172,6 +177,21 @@ def comm_block(raw, steps: int, halo_bytes_formula: int, per_rank_wait=None) -> 
     if per_rank_wait is not None:
         out["wait_ms_per_step_by_rank"] = [round(float(v), 4) for v in per_rank_wait]
     return out
+
+
+def step_traffic_of(rec: dict):
+    """HBM bytes of one steady-state step from a workload's record in profiles/pmc_traffic.json (tools/summarize_profile.py):
+    the sum over the step's kernels of launches per step x counter bytes per launch, or None when the record has no such
+    table or one of the step's kernels has no counter value."""
+    st = (rec or {}).get("step")
+    if not st or st.get("kernels_without_counters"):
+        return None
+    tot = 0.0
+    for e in st.get("kernels", []):
+        if e.get("hbm_bytes_per_launch") is None:
+            return None
+        tot += e["launches_per_step"] * e["hbm_bytes_per_launch"]
+    return tot or None
 
 
 def host_cpu_budget():
@@ -509,10 +529,14 @@ def main():
         # the transport decision of the real run, which needs no GPU either: all ranks leave non-zero if one cannot bind RCCL
         native_dry = transport_or_exit(G.load_package(), torch, dist, rank, (world > 1 or args.force_slab) and args.backend == "nccl",
                                        args.allow_fallback_transport)
+        ipc_env = [os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")]
         if dist is not None:
             dist.barrier()
+            ipc_env = [None] * world
+            dist.all_gather_object(ipc_env, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
         if rank == 0:
             print(json.dumps({"metric": "MLUPS (full EK-PNP step)", "value": None, "unit": "MLUPS", "n_gpus": world, "dry_run": True, "scaling": sel["scaling"],
+                              "env_by_rank": {"HSA_ENABLE_IPC_MODE_LEGACY": ipc_env},  # what the ranks of THIS launch mode run with
                               "transport": ("none (one context)" if world == 1 and not args.force_slab else
                                             "RCCL inside libekpnp.so" if native_dry else
                                             "torch.distributed example transport (rehearsal / FALLBACK)"),
@@ -729,12 +753,16 @@ def main():
         # HBM traffic of one launch from the PMC counters: NOT measured by this run (counters need
         # rocprofv3 around the process) - the value of the committed profile of this workload, with
         # where it comes from; null if the profile does not cover this workload
-        traffic, traffic_src = None, None
+        traffic, traffic_src, step_traffic = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath)).get(wname, {})
                 traffic = rec.get("hbm_bytes_per_launch")
+                # what the whole step moves by the same counters (every kernel of a step x its launches): only for the
+                # code path that profile ran - one context, two population buffers
+                if not slab_path and not p.in_place:
+                    step_traffic = step_traffic_of(rec)
                 traffic_src = None if traffic is None else {"file": "profiles/pmc_traffic.json", "profiled_in": rec.get("round"),
                                "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of that committed profile, NOT measured by this run"}
             except Exception:
@@ -765,6 +793,12 @@ def main():
                 "ic": ic_note + (" + closed-form 3-D perturbation" if args.ic == "perturbed" else ""),
                 "b_alg_step_bytes_per_node": b_alg_step(nl),
                 "step_roofline_frac": round(b_alg_step(nl) * mlups / world * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
+                # the yardstick above credits SURVEY 8(d)'s compulsory bytes (1 856 B/node at cfg3).  What the step REALLY
+                # moves, summed over all its kernels from the committed counter profile of this workload (NOT measured by
+                # this run; null without such a profile), and the HBM rate that is at this run's step time
+                "step_traffic_bytes": None if step_traffic is None else int(step_traffic),
+                "step_hbm_GBps": None if step_traffic is None else round(step_traffic / (dt / args.steps) / 1e9, 1),
+                "step_traffic_over_algorithmic": None if step_traffic is None else round(step_traffic / (b_alg_step(nl) * nodes_total), 4),
                 "device_bytes": sol.device_bytes(),
                 # arenas the context timed at creation and the one it kept (tried 0: the arena is most of the device - cfg3, cfg5)
                 "placement": sol.placement_report(),

@@ -179,3 +179,51 @@ def test_the_package_has_no_second_data_path():
             for verb in ("P2POp", "isend", "irecv", "all_gather", "all_reduce", "init_process_group", "batch_isend_irecv"):
                 assert verb not in txt, (name, verb)  # nothing in the package moves data (or anything else) through torch.distributed
     assert os.path.exists(os.path.join(ROOT, "examples", "host_transport.py"))
+
+
+def test_ranks_launched_by_torch_distributed_run_get_the_ipc_mode_too():
+    """`python -m torch.distributed.run ... bench.py --gpus N` is the DRIVER's launch, and its ranks
+    used to start without HSA_ENABLE_IPC_MODE_LEGACY=0 (only bench.py's own spawn_ranks set it) - RCCL across processes
+    fails without it on this pool.  bench.py now sets it at import, before torch; the dry run reports what every rank has."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert out["env_by_rank"]["HSA_ENABLE_IPC_MODE_LEGACY"] == ["0", "0"]
+    # an explicit setting of the caller is respected, not overwritten
+    r = subprocess.run(cmd, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])["env_by_rank"]["HSA_ENABLE_IPC_MODE_LEGACY"] == ["1", "1"]
+
+
+def test_step_traffic_comes_from_the_committed_counter_table():
+    """the line says what the step REALLY moves (all kernels, counter bytes), beside the 1 856 B/node
+    yardstick.  profiles/pmc_traffic.json carries the per-kernel table; bench.step_traffic_of sums it."""
+    import json
+
+    b = _bench()
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["cfg3"]
+    st = rec["step"]
+    names = " ".join(e["kernel"] for e in st["kernels"])
+    for k in ("k_collide_bulk<4, true, true>", "k_collide_wall<4, true, true>", "k_fft_x_r2c<512>", "k_fft_x_c2r<512>", "k_fft_y512", "k_tridiag_part<8, 64>"):
+        assert k in names, k
+    tot = b.step_traffic_of(rec)
+    assert abs(tot - st["hbm_bytes_per_step"]) < 1.0
+    alg = b.b_alg_step(4) * 512**3
+    # lazy E: the step moves LESS than the yardstick's Poisson I/O (no E arrays) and more for the transform passes: 1.0 - 1.06 x
+    assert 1.0 <= tot / alg <= 1.06, tot / alg
+    assert b.step_traffic_of({}) is None and b.step_traffic_of({"step": {"kernels": [{"kernel": "k", "launches_per_step": 1, "hbm_bytes_per_launch": None}]}}) is None
+    # the keys are in the line bench.py prints
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"step_traffic_bytes"', '"step_hbm_GBps"', '"step_roofline_frac"'):
+        assert key in src

@@ -141,6 +141,45 @@ def test_fluid_only_poiseuille(pkg, O):
     assert abs(ux[0] + ux[1]) < 1e-12 * abs(ux[1])
 
 
+def test_cfg1_at_its_own_size_on_the_hip_path(pkg, O):
+    """BASELINE.json configs[0] as it is written: 64x64x64, fluid lattice only (`k_collide_bulk<1, ...>` and the one-lattice
+    plates), exf = 1e9, chargeinf = Ra = TH = 0 - the workload bench.py's cpu_baseline times on the oracle, here through
+    the HIP path.  200 steps against the oracle at TOL, then the fluid wall rule cfg1 isolates
+    (LBM.cu:1848-1961): ux(0) = -ux(1) exactly (the z == 0 override, LBM.cu:663-801), and the total mass of the lattice
+    conserved to rounding (1e-13).  A second run starts from the x-y structured perturbation so that a
+    swapped or mirrored direction of the one-lattice instantiation cannot hide behind the x-y uniform channel."""
+    po = O.default_params(64, 64, 64)
+    po.n_lattices, po.chargeinf, po.Ra, po.TH, po.exf, po.pb_iterations = 1, 0.0, 0.0, 0.0, 1e9, 1
+    groups = {"rho": ["rho"], "u": ["ux", "uy", "uz"]}
+    orc = O.Oracle(po)
+    try:
+        orc.initialization(); orc.init_equilibrium()
+        with pkg.Solver(_mirror(pkg, po)) as s:
+            s.initialization(); s.init_equilibrium()
+            s.step(1); orc.step(1)
+            m0 = float(s.get_field("rho").sum(dtype=np.float64))
+            for mark, n in ((50, 49), (200, 150)):
+                s.step(n); orc.step(n)
+                e = O.rel_l2(s.fields(), orc.fields(), groups)
+                _REPORT.append({"test": "test_cfg1_at_its_own_size_on_the_hip_path", "mark": str(mark), "rel_l2": e})
+                assert e["rho"] <= TOL and e["u"] <= TOL_U, (mark, e)
+            f = s.fields()
+            assert np.abs(f["ux"]).max() > 0 and np.array_equal(f["ux"][0], -f["ux"][1])
+            assert abs(float(f["rho"].sum(dtype=np.float64)) - m0) <= 1e-12 * abs(m0)
+            # the Poiseuille profile is on its way: x-y uniform, parabolic sign (fastest in the middle)
+            assert np.ptp(f["ux"][32]) <= 1e-9 * abs(f["ux"][32]).max() and f["ux"][32, 0, 0] > f["ux"][2, 0, 0] > 0
+        # x-y structure
+        start = O.perturb_fields(po, orc.fields())
+        orc.set_fields(start); orc.init_equilibrium(); orc.step(20)
+        with pkg.Solver(_mirror(pkg, po)) as s:
+            s.set_fields(start); s.init_equilibrium(); s.step(20)
+            e = O.rel_l2(s.fields(), orc.fields(), groups)
+            _REPORT.append({"test": "test_cfg1_at_its_own_size_on_the_hip_path", "mark": "perturbed 20", "rel_l2": e})
+            assert e["rho"] <= TOL and e["u"] <= TOL_U, e
+    finally:
+        orc.close()
+
+
 def test_moving_wall_and_body_force(pkg, O):
     po = O.default_params(20, 6, 11)
     po.pb_iterations = 10

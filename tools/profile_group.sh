@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 "$ROOT/tools/group_overhead.py" "$GRID" "$NS" 10 --group-only > "$OUT/trace.log" 2>&1 || { tail -5 "$OUT/trace.log"; exit 1; }
 T=$(find "$OUT" -name "*kernel_trace.csv" | head -1)
 S=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
-python3 "$ROOT/tools/gpu_busy_from_trace.py" "$T" 8 k_halo_unpack "$NS" > "$ROOT/gpurun_out/${TAG}_group_gpu_busy.json" && cp "$S" "$ROOT/gpurun_out/${TAG}_group_kernel_stats.csv"
+python3 "$ROOT/tools/gpu_busy_from_trace.py" "$T" 8 > "$ROOT/gpurun_out/${TAG}_group_gpu_busy.json" && cp "$S" "$ROOT/gpurun_out/${TAG}_group_kernel_stats.csv"
 tail -1 "$OUT/trace.log" >> "$ROOT/gpurun_out/${TAG}_group_gpu_busy.json"
 rm -rf "$OUT/trace"
 cat "$ROOT/gpurun_out/${TAG}_group_gpu_busy.json"

@@ -13,8 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 "$ROOT/bench.py" --force-slab --no-cpu-baseline --steps 8 --warmup 2 "$@" > "$OUT/trace.log" 2>&1 || { tail -5 "$OUT/trace.log"; exit 1; }
 T=$(find "$OUT" -name "*kernel_trace.csv" | head -1)
 S=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
-python3 "$ROOT/tools/overlap_trace.py" "$T" > "$ROOT/gpurun_out/${TAG}_slab_overlap.json" && cp "$S" "$ROOT/gpurun_out/${TAG}_slab_kernel_stats.csv"
-python3 "$ROOT/tools/step_timeline.py" "$T" > "$ROOT/gpurun_out/${TAG}_slab_last_step_timeline.json" 2>/dev/null || true
+python3 "$ROOT/tools/overlap_trace.py" "$T" > "$ROOT/gpurun_out/${TAG}_slab_overlap.json" || { echo "overlap_trace found no step: stale tool?"; exit 1; }
+cp "$S" "$ROOT/gpurun_out/${TAG}_slab_kernel_stats.csv"
+python3 "$ROOT/tools/step_timeline.py" "$T" > "$ROOT/gpurun_out/${TAG}_slab_last_step_timeline.json" || true
+python3 "$ROOT/tools/trace_steps.py" --excerpt "$T" "$ROOT/gpurun_out/${TAG}_slab_trace_excerpt_last_3_steps.csv" 3 || true
 grep '"metric"' "$OUT/trace.log" | tail -1 > "$ROOT/gpurun_out/${TAG}_slab_bench_line_under_profiler.json"
 rm -rf "$OUT/trace"   # the per-dispatch trace is large; the three summaries above are what is kept
 head -c 1500 "$ROOT/gpurun_out/${TAG}_slab_overlap.json"

@@ -48,6 +48,21 @@ tpath = os.path.join(dst, "pmc_traffic.json")
 t = json.load(open(tpath)) if os.path.exists(tpath) else {}
 t[wl] = {"kernel": bulk, "hbm_bytes_per_launch": out["kernels"][bulk]["hbm_bytes_per_launch"], "round": tag,
          "note": "(FETCH_SIZE*fetch_factor + WRITE_SIZE)*1024, separate --pmc passes, calibrated on tools/pmc_calib"}
+# what one STEADY-STATE STEP moves, kernel by kernel: the kernels between two consecutive launches of the sweep in the
+# per-dispatch trace of pass 1 (the last full step), each with the counter bytes of its launch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from trace_steps import load_rows  # noqa: E402
+
+trace = os.path.join(src, "trace", "trace_kernel_trace.csv")
+if os.path.exists(trace):
+    rows = load_rows(trace)
+    gmax = max(r["gx"] for r in rows if r["n"] == bulk)
+    marks = [i for i, r in enumerate(rows) if r["n"] == bulk and r["gx"] == gmax]
+    step = collections.Counter(r["n"] for r in rows[marks[-2]:marks[-1]])
+    table = [{"kernel": k, "launches_per_step": n, "hbm_bytes_per_launch": out["kernels"].get(k, {}).get("hbm_bytes_per_launch")} for k, n in sorted(step.items())]
+    t[wl]["step"] = {"kernels": table, "hbm_bytes_per_step": sum(e["launches_per_step"] * (e["hbm_bytes_per_launch"] or 0.0) for e in table),
+                     "kernels_without_counters": [e["kernel"] for e in table if e["hbm_bytes_per_launch"] is None],
+                     "note": "kernels of the last full step of the kernel trace x the counter bytes of their launches (same profile); bench.py prints the sum as config.step_traffic_bytes"}
 json.dump(t, open(tpath, "w"), indent=1)
 for f in ("calib_fetch.log",):
     shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_pmc_calib.log"))

@@ -89,6 +89,16 @@ __global__ void k_poisson_rhs(PArgs a) {
   a.work[i] = v;
 }
 
+// A mode BLOCK of a slab's z solve: the (kx, ky) modes with bx0 <= kx < bx0 + bw, numbered j = ky bw + (kx - bx0), so that the
+// edge values of a block are one contiguous piece [4][ny bw] of the exchange buffers and the all-gather of one block can run
+// while the next block is still being transformed (slab_team.hip: "edge_chunks").  The whole half spectrum is the block
+// bx0 = 0, bw = nxh, where j is the mode index itself.
+__device__ __forceinline__ long long block_mode(const PArgs& a, long long j) {
+  if (a.bw == a.nxh) return j;
+  const long long ky = j / a.bw;
+  return ky * a.nxh + a.bx0 + (j - ky * a.bw);
+}
+
 // Diagonal of the z system of one (kx,ky) mode:  phi[z-1] + b phi[z] + phi[z+1] = dz^2 g[z],
 // b = -(2 + dz^2 (kx^2 + ky^2)), wavenumbers exactly as main.cu:119-136.  (Pad columns of the half
 // spectrum get some b <= -2 too: their right-hand side is 0 and stays 0.)
@@ -268,9 +278,10 @@ struct TriPart {
   static constexpr int IMAGE = LANES * R * MC;  // double2 elements of one LDS image [LANES R slots][MC columns] = R x 8 KB
 
   // the workgroup's rows of mode group m0 .. m0 + MC - 1, coalesced (thread (c, t): rows t + TR r of column c), into registers
-  static __device__ __forceinline__ void load(const double2* __restrict__ rows, long long ms, long long m0, int n, double2 (&v)[R], const int tid = threadIdx.x) {
-    const int c = tid % MC, t = tid / MC;
-    const double2* src = rows + m0 + c;
+  // (mcol: the mode of THIS thread's column c = tid % MC - m0 + c, or its image under block_mode() for a mode block of a slab)
+  static __device__ __forceinline__ void load(const double2* __restrict__ rows, long long ms, long long mcol, int n, double2 (&v)[R], const int tid = threadIdx.x) {
+    const int t = tid / MC;
+    const double2* src = rows + mcol;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s = t + TR * r;
@@ -288,9 +299,9 @@ struct TriPart {
     }
   }
   // LDS image -> global, the way the rows came
-  static __device__ __forceinline__ void store(double2* __restrict__ rows, long long ms, long long m0, int n, const double2* __restrict__ img, const int tid = threadIdx.x) {
+  static __device__ __forceinline__ void store(double2* __restrict__ rows, long long ms, long long mcol, int n, const double2* __restrict__ img, const int tid = threadIdx.x) {
     const int c = tid % MC, t = tid / MC;
-    double2* dst = rows + m0 + c;
+    double2* dst = rows + mcol;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s = t + TR * r;
@@ -305,11 +316,10 @@ template <int R, int LANES, bool SLAB, int NW = 8>
 __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __restrict__ img, const long long m0, const int n, const double* __restrict__ bound) {
   using TP = TriPart<R, LANES, NW>;
   constexpr int MPW = TP::MPW, MC = TP::MC, FM = TP::FM;
-  const long long ms = (long long)a.ny * a.nxh;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l = lane % LANES;                 // lane within its mode: owns slots R l .. R l + R - 1
   const int col = w * MPW + lane / LANES;     // the mode among the workgroup's MC
-  const double b = mode_diag((int)(m0 + col), a.ny, a.nxh, a.Lx, a.Ly, a.dz);
+  const double b = mode_diag((int)(SLAB ? block_mode(a, m0 + col) : m0 + col), a.ny, a.nxh, a.Lx, a.Ly, a.dz);
   const double dz2 = a.dz * a.dz;
   double2* mine = img + (R * l) * MC + (col ^ (l & FM));
   double2 g[R];
@@ -319,8 +329,9 @@ __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __re
     g[k] = make_double2(dz2 * r.x, dz2 * r.y);
   }
   if (SLAB) {
+    const long long msl = (long long)a.ny * a.bw;  // the boundary values are stored by mode BLOCK: [4][ny bw], local numbering
     const double* bw = bound + m0 + col;
-    const double glr = bw[0], gli = bw[ms], ghr = bw[2 * ms], ghi = bw[3 * ms];
+    const double glr = bw[0], gli = bw[msl], ghr = bw[2 * msl], ghi = bw[3 * msl];
     if (l == 0) g[0] = make_double2(g[0].x - glr, g[0].y - gli);
 #pragma unroll
     for (int k = 0; k < R; ++k)
@@ -402,16 +413,17 @@ __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __res
   using TP = TriPart<R, LANES, NW>;
   extern __shared__ double2 tp_lds[];    // [LANES R slots][MC columns] = R x NW KB
   const long long ms = (long long)a.ny * a.nxh;
-  const long long m0 = (long long)blockIdx.x * TP::MC;
+  const long long m0 = (long long)blockIdx.x * TP::MC;  // SLAB: numbered within the kernel's mode block (block_mode)
+  const long long mcol = SLAB ? block_mode(a, m0 + threadIdx.x % TP::MC) : m0 + threadIdx.x % TP::MC;
   {
     double2 v[R];
-    TP::load(rows, ms, m0, n, v);
+    TP::load(rows, ms, mcol, n, v);
     TP::put(tp_lds, v);
   }
   __syncthreads();
   tridiag_part_solve<R, LANES, SLAB, NW>(a, tp_lds, m0, n, bound);
   __syncthreads();
-  TP::store(rows, ms, m0, n, tp_lds);
+  TP::store(rows, ms, mcol, n, tp_lds);
 }
 
 // What bounds this kernel, with counters, and the five restructurings that were built, measured and removed again in round 4
@@ -733,9 +745,10 @@ __global__ void k_slab_unit_response(const double* __restrict__ cprime, int m, i
 // stage 1: forward elimination of the owned unknown rows, in place; edges -> edge buffer
 // edge layout per rank: [4][nmodes] = p_first.re, p_first.im, p_last.re, p_last.im
 __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __restrict__ u, double* __restrict__ edge) {
-  const int md = blockIdx.x * blockDim.x + threadIdx.x;
-  const long long ms = (long long)a.ny * a.nxh;
-  if (md >= ms) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // mode within the block a.bx0, a.bw; edge: [4][ny bw]
+  const long long ms = (long long)a.ny * a.nxh, msl = (long long)a.ny * a.bw;
+  if (j >= msl) return;
+  const int md = (int)block_mode(a, j);
   const double dz2 = a.dz * a.dz;
   double2* s = a.spec + md + (long long)row_a * ms;  // local plane of the first unknown row
   const double b = mode_diag(md, a.ny, a.nxh, a.Lx, a.Ly, a.dz);
@@ -753,10 +766,10 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __r
     di = (ri - di) * c;
     if ((k & (TRI_BS - 1)) == 0) s[(long long)(k - 1) * ms] = make_double2(dr, di);  // checkpoint, as in k_tridiag
   }
-  edge[md] = p1r;           // p_1 = u . r
-  edge[ms + md] = p1i;
-  edge[2 * ms + md] = dr;   // p_m = d'_m
-  edge[3 * ms + md] = di;
+  edge[j] = p1r;             // p_1 = u . r
+  edge[msl + j] = p1i;
+  edge[2 * msl + j] = dr;    // p_m = d'_m
+  edge[3 * msl + j] = di;
 }
 
 // stage 1 of the read-once slab solve (round 3): ONLY the two edge values, as dot products.  A is symmetric and
@@ -774,9 +787,10 @@ __global__ void __launch_bounds__(64 * EDGE_SEGS) k_slab_edges(PArgs a, int row_
   __shared__ double part[EDGE_SEGS][4][64];
   __shared__ int kmax_s;
   const int tx = threadIdx.x & 63, seg = threadIdx.x >> 6;
-  const long long ms = (long long)a.ny * a.nxh;
-  const long long md = (long long)blockIdx.x * 64 + tx;
-  const bool live = md < ms;
+  const long long ms = (long long)a.ny * a.nxh, msl = (long long)a.ny * a.bw;
+  const long long jm = (long long)blockIdx.x * 64 + tx;  // mode within the block a.bx0, a.bw; edge: [4][ny bw]
+  const bool live = jm < msl;
+  const long long md = live ? block_mode(a, jm) : 0;
   int K = 0;
   if (live) {
     const double b = mode_diag((int)md, a.ny, a.nxh, a.Lx, a.Ly, a.dz);
@@ -821,7 +835,7 @@ __global__ void __launch_bounds__(64 * EDGE_SEGS) k_slab_edges(PArgs a, int row_
     double acc = part[0][seg][tx];
 #pragma unroll
     for (int g = 1; g < EDGE_SEGS; ++g) acc += part[g][seg][tx];
-    edge[(long long)seg * ms + md] = dz2 * acc;
+    edge[(long long)seg * msl + jm] = dz2 * acc;
   }
 }
 
@@ -837,26 +851,27 @@ constexpr int MAXR = 16;
 // split, profiles/r02_slab_after_kernel_stats.csv)
 __global__ void k_slab_interface(PArgs a, int rank, int nranks, const double* __restrict__ edges_all, const double* __restrict__ u1um_all,
                                  double* __restrict__ g) {
-  const int md = blockIdx.x * blockDim.x + threadIdx.x;
-  const long long ms = (long long)a.ny * a.nxh;
-  if (md >= ms) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // mode within the block a.bx0, a.bw; edges_all: [nranks][4][ny bw], g: [4][ny bw]
+  const long long ms = (long long)a.ny * a.nxh, msl = (long long)a.ny * a.bw;
+  if (j >= msl) return;
+  const int md = (int)block_mode(a, j);
   const int ni = nranks - 1;
   double u1[MAXR], um[MAXR];
-  for (int j = 0; j < nranks; ++j) {
-    const double* t = u1um_all + (long long)j * 2 * ms;  // (u_1, u_m) of rank j's block (its own row count)
-    u1[j] = t[md];
-    um[j] = t[ms + md];
+  for (int q = 0; q < nranks; ++q) {
+    const double* t = u1um_all + (long long)q * 2 * ms;  // (u_1, u_m) of rank q's block (its own row count)
+    u1[q] = t[md];
+    um[q] = t[ms + md];
   }
   // block Thomas.  D_i = [[1, u1_i],[u1_{i+1}, 1]], L_i = [[um_i,0],[0,0]], U_i = [[0,0],[0,um_{i+1}]]
   // forward: D'_i = D_i - L_i D'^{-1}_{i-1} U_{i-1};  R'_i = R_i - L_i D'^{-1}_{i-1} R'_{i-1}
   double d11[MAXR], d12[MAXR], d21[MAXR], d22[MAXR];
   double rxr[MAXR], rxi[MAXR], ryr[MAXR], ryi[MAXR];
   for (int i = 0; i < ni; ++i) {
-    const double* ei = edges_all + (long long)i * 4 * ms;        // slab i
-    const double* ej = edges_all + (long long)(i + 1) * 4 * ms;  // slab i+1
+    const double* ei = edges_all + (long long)i * 4 * msl;        // slab i
+    const double* ej = edges_all + (long long)(i + 1) * 4 * msl;  // slab i+1
     double a11 = 1.0, a12 = u1[i], a21 = u1[i + 1], a22 = 1.0;
-    double bxr = ei[2 * ms + md], bxi = ei[3 * ms + md];  // p_last(i)
-    double byr = ej[md], byi = ej[ms + md];               // p_first(i+1)
+    double bxr = ei[2 * msl + j], bxi = ei[3 * msl + j];  // p_last(i)
+    double byr = ej[j], byi = ej[msl + j];                // p_first(i+1)
     if (i > 0) {
       // L_i D'^{-1}_{i-1}: only row 0, L = [[um_i,0],[0,0]] -> row0 = um_i * (first row of D'^{-1})
       const double det = d11[i - 1] * d22[i - 1] - d12[i - 1] * d21[i - 1];
@@ -885,17 +900,18 @@ __global__ void k_slab_interface(PArgs a, int rank, int nranks, const double* __
     Yi[i] = (-d21[i] * bxi + d11[i] * byi) / det;
   }
   // the two values this rank's rows see: x just below its first row, x just above its last row
-  g[md] = rank > 0 ? Xr[rank - 1] : 0.0;
-  g[ms + md] = rank > 0 ? Xi[rank - 1] : 0.0;
-  g[2 * ms + md] = rank < nranks - 1 ? Yr[rank] : 0.0;
-  g[3 * ms + md] = rank < nranks - 1 ? Yi[rank] : 0.0;
+  g[j] = rank > 0 ? Xr[rank - 1] : 0.0;
+  g[msl + j] = rank > 0 ? Xi[rank - 1] : 0.0;
+  g[2 * msl + j] = rank < nranks - 1 ? Yr[rank] : 0.0;
+  g[3 * msl + j] = rank < nranks - 1 ? Yi[rank] : 0.0;
 }
 
 __global__ void __launch_bounds__(64) k_slab_reduce_correct(PArgs a, int row_a, int m, const double* __restrict__ g, const double* __restrict__ w) {
-  const int md = blockIdx.x * blockDim.x + threadIdx.x;
-  const long long ms = (long long)a.ny * a.nxh;
-  if (md >= ms) return;
-  const double glr = g[md], gli = g[ms + md], ghr = g[2 * ms + md], ghi = g[3 * ms + md];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // mode within the block a.bx0, a.bw; g: [4][ny bw]
+  const long long ms = (long long)a.ny * a.nxh, msl = (long long)a.ny * a.bw;
+  if (j >= msl) return;
+  const int md = (int)block_mode(a, j);
+  const double glr = g[j], gli = g[msl + j], ghr = g[2 * msl + j], ghi = g[3 * msl + j];
   // back substitution of A x = r - g_lo e_1 - g_hi e_m; d' is recomputed block by block from the
   // checkpoints stage 1 left in every TRI_BS-th row (as in k_tridiag)
   double2* s = a.spec + md + (long long)row_a * ms;

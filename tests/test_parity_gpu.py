@@ -145,7 +145,7 @@ def test_cfg1_at_its_own_size_on_the_hip_path(pkg, O):
     """BASELINE.json configs[0] as it is written: 64x64x64, fluid lattice only (`k_collide_bulk<1, ...>` and the one-lattice
     plates), exf = 1e9, chargeinf = Ra = TH = 0 - the workload bench.py's cpu_baseline times on the oracle, here through
     the HIP path.  200 steps against the oracle at TOL, then the fluid wall rule cfg1 isolates
-    (LBM.cu:1848-1961): ux(0) = -ux(1) exactly (the z == 0 override, LBM.cu:663-801), and the total mass of the lattice
+    (LBM.cu:1848-1961): rho(0) ux(0) = -rho(1) ux(1) to the last bit or two (the z == 0 override, LBM.cu:663-801), and the total mass of the lattice
     conserved to rounding (1e-13).  A second run starts from the x-y structured perturbation so that a
     swapped or mirrored direction of the one-lattice instantiation cannot hide behind the x-y uniform channel."""
     po = O.default_params(64, 64, 64)
@@ -164,7 +164,10 @@ def test_cfg1_at_its_own_size_on_the_hip_path(pkg, O):
                 _REPORT.append({"test": "test_cfg1_at_its_own_size_on_the_hip_path", "mark": str(mark), "rel_l2": e})
                 assert e["rho"] <= TOL and e["u"] <= TOL_U, (mark, e)
             f = s.fields()
-            assert np.abs(f["ux"]).max() > 0 and np.array_equal(f["ux"][0], -f["ux"][1])
+            # ux(0) = -ux(1) up to the ratio rho(1)/rho(0): the override divides node 1's momentum by node 0's density
+            # (`rhoinvm = 1.0/rho`, LBM.cu:780), and the two densities differ in their last bits (oracle: 2.9e-15)
+            assert np.abs(f["ux"]).max() > 0 and np.abs(f["ux"][0] + f["ux"][1]).max() <= 1e-13 * np.abs(f["ux"][1]).max()
+            assert np.abs(f["ux"][0] * f["rho"][0] + f["ux"][1] * f["rho"][1]).max() <= 4e-16 * np.abs(f["ux"][1] * f["rho"][1]).max()
             assert abs(float(f["rho"].sum(dtype=np.float64)) - m0) <= 1e-12 * abs(m0)
             # the Poiseuille profile is on its way: x-y uniform, parabolic sign (fastest in the middle)
             assert np.ptp(f["ux"][32]) <= 1e-9 * abs(f["ux"][32]).max() and f["ux"][32, 0, 0] > f["ux"][2, 0, 0] > 0

@@ -13,6 +13,7 @@ from .solver import (  # noqa: F401
     EkpnpError,
     Group,
     Params,
+    STAGE_NAMES,
     Solver,
     TRANSPORT_AUTO,
     TRANSPORT_COPY,

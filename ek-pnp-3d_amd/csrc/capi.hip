@@ -98,11 +98,15 @@ hipError_t take_launch_error(Ctx& c) {
 
 static void drop_graph(Ctx& c);
 
-// measurement hook (tools/sweep_zchunk.py): change a launch-shape knob of a live context
-extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
-  if (!ctx || !knob) return EKPNP_ERR_INVALID;
-  Ctx& c = ctx->c;
+namespace ekpnp {
+int ctx_tune(Ctx& c, const char* knob, int value) {
   if (std::strcmp(knob, "ab_zchunk") == 0 && value >= 0) { c.ab_zchunk = value; return EKPNP_OK; }
+  // slab launch shapes (same bits either way): the lead-in launch of the interior sweep, one launch for both faces
+  if (std::strcmp(knob, "lead_planes") == 0 && value >= 0 && c.slab) { c.lead_planes = value; return EKPNP_OK; }
+  if (std::strcmp(knob, "merged_faces") == 0 && (value == 0 || value == 1) && c.slab) { c.merged_faces = value != 0; return EKPNP_OK; }
+  // mode blocks of the slab z solve: the layout of the edge buffers changes with it, so only a context whose exchanges the
+  // library moves itself may ask for more than one (an external transport gathers the whole buffer in one piece)
+  if (std::strcmp(knob, "edge_chunks") == 0 && value >= 1 && value <= 16 && c.slab && (value == 1 || c.team)) { c.edge_chunks = value; return EKPNP_OK; }
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_wide") == 0 && (value == 0 || value == 1)) { c.tri_wide = value != 0 && c.tri_lds_ok && tridiag_wide_prepare_device(); drop_graph(c); return EKPNP_OK; }
@@ -112,8 +116,18 @@ extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
     drop_graph(c);
     return rc;
   }
-  c.err = "ekpnp_tune: unknown knob or bad value";
+  c.err = std::string("ekpnp_tune: unknown knob or bad value: ") + knob + " = " + std::to_string(value);
   return EKPNP_ERR_INVALID;
+}
+}  // namespace ekpnp
+
+// measurement hook (tools/sweep_zchunk.py, bench.py's comm_ab): change a launch-shape or transport knob of a live context
+extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
+  if (!ctx || !knob) return EKPNP_ERR_INVALID;
+  Ctx& c = ctx->c;
+  // the transport's own knobs first (an attached slab; the members of an in-process group are tuned through ekpnp_group_tune)
+  if (c.team && (std::strcmp(knob, "inline_exchanges") == 0 || std::strcmp(knob, "comm_cus") == 0)) return team_ctx_tune(c, knob, value);
+  return ctx_tune(c, knob, value);
 }
 
 extern "C" int ekpnp_debug_sync_enabled(void) { return std::getenv("EKPNP_DEBUG_SYNC") != nullptr; }
@@ -244,6 +258,7 @@ PArgs Ctx::pargs() const {
   a.dx = p.dx; a.dy = p.dy; a.dz = p.dz;
   a.Lx = p.Lx; a.Ly = p.Ly;
   a.inv_nxny = 1.0 / ((double)p.nx * (double)p.ny);
+  a.bx0 = 0; a.bw = nxh;
   return a;
 }
 
@@ -322,6 +337,9 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
   if (const char* e = std::getenv("EKPNP_LAZY_E")) c.lazy_efield = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("EKPNP_HALO_DIRECT")) c.halo_direct = std::atoi(e) != 0;
+  if (const char* e = std::getenv("EKPNP_MERGED_FACES")) c.merged_faces = std::atoi(e) != 0;
+  if (const char* e = std::getenv("EKPNP_SLAB_LEAD_PLANES")) c.lead_planes = std::atoi(e) < 0 ? 0 : std::atoi(e);
+  if (const char* e = std::getenv("EKPNP_EDGE_CHUNKS")) c.edge_chunks = std::atoi(e) < 1 ? 1 : (std::atoi(e) > 16 ? 16 : std::atoi(e));
   {
     const char* e = std::getenv("EKPNP_TRI_WIDE");
     c.tri_wide = c.tri_lds_ok && (e ? std::atoi(e) != 0 : false) && tridiag_wide_prepare_device();
@@ -509,6 +527,8 @@ extern "C" int ekpnp_destroy(ekpnp_ctx* ctx) {
   if (c.have_inv) hipfftDestroy(c.plan_inv);
   for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : c.ev_poisson) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : c.ev_stage)
+    for (hipEvent_t ev : e) (void)hipEventDestroy(ev);
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
   delete ctx;
   return EKPNP_OK;
@@ -661,11 +681,23 @@ static int poisson_timing_mark(Ctx& c, bool begin) {
       HIPCHK(c, hipEventCreate(&b));
       c.ev_poisson.emplace_back(a, b);
     }
+    while (c.slab && c.ev_stage.size() < c.ev_poisson.size()) {
+      std::array<hipEvent_t, 4> st{};
+      for (hipEvent_t& ev : st) HIPCHK(c, hipEventCreate(&ev));
+      c.ev_stage.push_back(st);
+    }
     HIPCHK(c, hipEventRecord(c.ev_poisson[c.evp_used].first, c.stream));
   } else if (c.evp_used < c.ev_poisson.size()) {
     HIPCHK(c, hipEventRecord(c.ev_poisson[c.evp_used].second, c.stream));
     c.evp_used++;
   }
+  return EKPNP_OK;
+}
+
+// the marks inside a slab's solve (Ctx::ev_stage): 0 end of stage 1, 1 start of stage 2, 2 end of stage 2, 3 start of stage 3
+static int stage_mark(Ctx& c, int which) {
+  if (!c.timing || !c.slab || c.evp_used >= c.ev_stage.size()) return EKPNP_OK;
+  HIPCHK(c, hipEventRecord(c.ev_stage[c.evp_used][which], c.stream));
   return EKPNP_OK;
 }
 
@@ -1168,6 +1200,26 @@ extern "C" int ekpnp_phase_timing_get(ekpnp_ctx* ctx, int* n_solves, double* poi
   return EKPNP_OK;
 }
 
+extern "C" int ekpnp_poisson_stage_timing_get(ekpnp_ctx* ctx, int* n_solves, double* stage_ms) {
+  NEEDCTX(ctx);
+  if (!stage_ms) return fail(c, "stage_ms is NULL (5 doubles: stage 1, EDGE exchange, stage 2, PHI exchange, stage 3)");
+  for (int k = 0; k < 5; ++k) stage_ms[k] = 0.0;
+  if (n_solves) *n_solves = 0;
+  if (!c.slab) return EKPNP_OK;
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  const size_t n = c.evp_used < c.ev_stage.size() ? c.evp_used : c.ev_stage.size();
+  for (size_t i = 0; i < n; ++i) {
+    const hipEvent_t t[6] = {c.ev_poisson[i].first, c.ev_stage[i][0], c.ev_stage[i][1], c.ev_stage[i][2], c.ev_stage[i][3], c.ev_poisson[i].second};
+    for (int k = 0; k < 5; ++k) {
+      float ms = 0.f;
+      HIPCHK(c, hipEventElapsedTime(&ms, t[k], t[k + 1]));
+      stage_ms[k] += ms;
+    }
+  }
+  if (n_solves) *n_solves = (int)n;
+  return EKPNP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // z-slab interface; the transport between the calls is the caller's
 
@@ -1250,8 +1302,7 @@ extern "C" int ekpnp_collide_boundary_planes(ekpnp_ctx* ctx) {
       hi.B[l] = c.stage[l] + (ptrdiff_t)c.pplane - (ptrdiff_t)c.nzl * (ptrdiff_t)c.pplane;  // plane zg = nzl -> staging plane 1
     }
   }
-  static const bool merged_faces = !(std::getenv("EKPNP_MERGED_FACES") && std::atoi(std::getenv("EKPNP_MERGED_FACES")) == 0);  // A/B knob
-  if (c.halo_direct && merged_faces) {
+  if (c.halo_direct && c.merged_faces) {  // (A/B knob: EKPNP_MERGED_FACES / ekpnp_tune "merged_faces")
     launch_collide_faces(c, lo, hi);  // both faces, plate or not, in one launch
   } else {
     launch_collide_walls(c, lo, c.stream, true, false);
@@ -1279,7 +1330,7 @@ extern "C" int ekpnp_collide_interior_planes(ekpnp_ctx* ctx) {
   // ended (rocprofv3: the exchange kernel ended 0.1 ms AFTER a 39 ms sweep,
   // profiles/r02_slab_overlap_before.json).  A short lead-in launch drains after ~0.1 ms and lets
   // them in; the rest of the sweep then runs beside the transfer.
-  static const int lead_env = std::getenv("EKPNP_SLAB_LEAD_PLANES") ? std::atoi(std::getenv("EKPNP_SLAB_LEAD_PLANES")) : 2;
+  const int lead_env = c.lead_planes;  // EKPNP_SLAB_LEAD_PLANES / ekpnp_tune "lead_planes", default 2
   // (in-place slabs sweep in launches of zchunk planes anyway, but the first of them is up to 64 planes = 5 ms
   // long on cfg3's planes: they get the same short lead-in, at the end of the lattice their ordered sweep starts from)
   const int lead = (lead_env > 0 && c.nzl - 2 > 4 * lead_env) ? lead_env : 0;
@@ -1306,9 +1357,8 @@ extern "C" int ekpnp_advance_time(ekpnp_ctx* ctx) {
   return EKPNP_OK;
 }
 
-extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
-  NEEDCTX(ctx);
-  if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+namespace ekpnp {
+int poisson_stage1_begin(Ctx& c) {
   distrust_bound_rhs(c);
   {
     int trc = poisson_timing_mark(c, true);
@@ -1316,10 +1366,43 @@ extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
   }
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
-  if (int frc = plane_fft_forward(c)) return frc;
-  launch_slab_thomas_local(c);
+  if (int frc = plane_fft_forward_rows(c)) return frc;
   LAUNCHCHK(c);
   return EKPNP_OK;
+}
+int poisson_stage1_block(Ctx& c, int k) {
+  plane_fft_forward_columns(c, mode_block(c, k));
+  launch_slab_thomas_local(c, k);
+  LAUNCHCHK(c);
+  return EKPNP_OK;
+}
+int poisson_stage1_end(Ctx& c) { return stage_mark(c, 0); }
+int poisson_stage2_block(Ctx& c, int k) {
+  if (k == 0) {
+    if (int mrc = stage_mark(c, 1)) return mrc;
+  }
+  launch_slab_reduce_correct(c, k);
+  plane_fft_inverse_columns(c, mode_block(c, k));
+  LAUNCHCHK(c);
+  return EKPNP_OK;
+}
+int poisson_stage2_end(Ctx& c) {
+  if (int frc = plane_fft_inverse_rows(c)) return frc;
+  launch_phi_halo_pack(c);
+  LAUNCHCHK(c);
+  return stage_mark(c, 2);
+}
+}  // namespace ekpnp
+
+// The exported stages are for a transport of the CALLER's between them, which gathers the edge buffer in one piece: they
+// refuse a context that was tuned to several mode blocks (only the library's own transport moves those).
+extern "C" int ekpnp_poisson_stage1(ekpnp_ctx* ctx) {
+  NEEDCTX(ctx);
+  if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+  if (edge_chunk_count(c) != 1) return fail(c, "ekpnp_poisson_stage1: edge_chunks > 1 lays the edge buffers out in mode blocks, which only the library's own transport exchanges");
+  if (int rc = poisson_stage1_begin(c)) return rc;
+  if (int rc = poisson_stage1_block(c, 0)) return rc;
+  return poisson_stage1_end(c);
 }
 
 extern "C" int ekpnp_poisson_edge_buffer(ekpnp_ctx* ctx, int gathered, double** dptr, size_t* n) {
@@ -1334,7 +1417,9 @@ extern "C" int ekpnp_poisson_edge_buffer(ekpnp_ctx* ctx, int gathered, double** 
 extern "C" int ekpnp_poisson_stage2(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
-  launch_slab_reduce_correct(c);
+  if (edge_chunk_count(c) != 1) return fail(c, "ekpnp_poisson_stage2: edge_chunks > 1 needs the library's own transport");
+  if (int rc = stage_mark(c, 1)) return rc;
+  launch_slab_reduce_correct(c, 0);
   if (int frc = plane_fft_inverse(c)) return frc;
   LAUNCHCHK(c);
   return EKPNP_OK;
@@ -1345,12 +1430,13 @@ extern "C" int ekpnp_phi_halo_pack(ekpnp_ctx* ctx) {
   if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
   launch_phi_halo_pack(c);
   LAUNCHCHK(c);
-  return EKPNP_OK;
+  return stage_mark(c, 2);
 }
 
 extern "C" int ekpnp_poisson_stage3(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "single-slab context: use ekpnp_fast_poisson");
+  if (int mrc = stage_mark(c, 3)) return mrc;
   // the phi planes of the neighbouring slabs have arrived (PHI exchange): either E is written now, or the next collide
   // forms it from phi and these very halo planes (which the next PHI exchange only overwrites after that collide)
   const bool lazy = c.phi_old == nullptr && lazy_efield_ok(c);  // not inside the Poisson-Boltzmann sweeps (ekpnp_pbe_begin .. ekpnp_pbe_end), see poisson_single

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hipfft/hipfft.h>
 
+#include <array>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -136,6 +137,13 @@ struct PArgs {
   long long plane;
   double F, eps, voltage, voltage2, dx, dy, dz, inv_nxny, Lx, Ly;
   double rhs_wall_lo, rhs_wall_hi;  // as in KArgs
+  int bx0, bw;                 // slab z solve: the mode block (kx in [bx0, bx0 + bw)) a launch works on; the whole spectrum: 0, nxh
+};
+
+// one mode block of a slab's z solve (poisson.hip: mode_block): its kx columns and its pieces of the edge buffers
+struct ModeBlock {
+  int x0, bw;
+  size_t local_off, all_off, doubles;  // offsets (doubles) into Ctx::edge_local / Ctx::edge_all; doubles per rank (= 4 ny bw)
 };
 
 struct Ctx;
@@ -168,8 +176,14 @@ void launch_tridiag(Ctx&);
 bool tridiag_prepare_device();  // per-device function attributes of the partition z solves (current device)
 bool tridiag_wide_prepare_device();  // ... of the 16-wavefront forms (128 KB of LDS)
 void launch_phi_efield(Ctx&);
-void launch_slab_thomas_local(Ctx&);
-void launch_slab_reduce_correct(Ctx&);
+void launch_slab_thomas_local(Ctx&, int block = 0);    // stage 1 of the slab z solve on mode block `block`
+void launch_slab_reduce_correct(Ctx&, int block = 0);  // stage 2 on mode block `block` (its edge values gathered)
+int edge_chunk_count(const Ctx&);                       // mode blocks of this context's slab solve (Ctx::edge_chunks, at most nxh / 8)
+ModeBlock mode_block(const Ctx&, int block);
+int plane_fft_forward_rows(Ctx&);                       // the transforms in pieces (rows of all planes / columns of one block)
+void plane_fft_forward_columns(Ctx&, const ModeBlock&);
+void plane_fft_inverse_columns(Ctx&, const ModeBlock&);
+int plane_fft_inverse_rows(Ctx&);
 void launch_phi_halo_pack(Ctx&);
 // diag.hip
 constexpr int DIAG_SCRATCH = 1024 + 8;
@@ -247,12 +261,16 @@ struct Ctx {
   double* u1um = nullptr;          // (u_1, u_m) of EVERY rank's block, [nranks][2][modes] (slabs may differ by one plane)
   double* edge_local = nullptr;    // [4][modes]
   double* edge_all = nullptr;      // [nranks][4][modes]
+  int edge_chunks = 1;             // mode blocks of the slab z solve (ekpnp_tune "edge_chunks" on a context with a transport, EKPNP_EDGE_CHUNKS):
+                                   // > 1: the EDGE all-gather of block k runs on the comm stream beside the column pass of block k + 1
   double* phi_old = nullptr;       // PB relaxation state (ekpnp_pbe_begin/end)
   double* diag = nullptr;          // reduction scratch (DIAG_SCRATCH doubles)
   double* vwall = nullptr;         // {voltage, voltage, voltage2, voltage2}
   int collide_phase = 0;           // 0 idle, 1 boundary planes done
   // slab edge planes without pack / unpack copies (KArgs::halo_*): knob, and where the current halos are
   bool halo_direct = true;         // EKPNP_HALO_DIRECT=0: k_halo_pack / k_halo_unpack as in rounds 1-3 (the A/B partner)
+  bool merged_faces = true;        // both faces of a slab in ONE launch (k_collide_faces); 0: a launch per face (EKPNP_MERGED_FACES, ekpnp_tune "merged_faces")
+  int lead_planes = 2;             // planes of the short lead-in launch in front of the interior sweep (EKPNP_SLAB_LEAD_PLANES, ekpnp_tune "lead_planes"; 0: none)
   bool halo_sent = false;          // the boundary-plane launches of this step have filled the send buffers already
   bool halo_recv_valid = false;    // the receive buffers hold what the next pull of the edge planes needs (else: the ghost planes do)
   // hipGraph of two consecutive steps (A->B, B->A) for launch-bound lattices
@@ -280,6 +298,9 @@ struct Ctx {
   size_t ev_used = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_poisson;  // the same around every Poisson solve (all its stages)
   size_t evp_used = 0;
+  // slabs: four marks inside solve i (same index as ev_poisson): end of stage 1, start of stage 2 (the EDGE exchange lies between
+  // the two), end of stage 2 + phi pack, start of stage 3 (the PHI exchange lies between) - ekpnp_poisson_stage_timing_get
+  std::vector<std::array<hipEvent_t, 4>> ev_stage;
   long long timed_nodes = 0;
   std::string err;
 
@@ -318,6 +339,14 @@ int team_ctx_initialization(Ctx&);
 int team_ctx_initialization_converged(Ctx&, double rel_tol, int max_sweeps, int* sweeps, double* residual);
 int team_ctx_reduce(Ctx&, double* value, bool is_max);  // combine a per-slab diagnostic over the ranks
 int team_ctx_turns(Ctx&, int (*fn)(Ctx&, void*), void* arg);  // fn on every slab in rank order (file IO)
+int team_ctx_tune(Ctx&, const char* knob, int value);  // the transport's knobs (ekpnp_tune on an attached slab): EKPNP_OK, or EKPNP_ERR_INVALID with a message for an unknown knob / bad value
+// capi.hip: the slab solve in pieces, driven by slab_team.hip around the exchanges (the exported ekpnp_poisson_stage1/2/3 are built from them)
+int poisson_stage1_begin(Ctx&);          // right-hand side + row pass (rocFFT plans: the whole forward transform)
+int poisson_stage1_block(Ctx&, int k);   // column pass of mode block k + its edge values -> edge_local
+int poisson_stage1_end(Ctx&);            // (measurement mark)
+int poisson_stage2_block(Ctx&, int k);   // interface system + z solve of mode block k (its edge values gathered) + inverse column pass
+int poisson_stage2_end(Ctx&);            // inverse row pass (rocFFT plans: the whole inverse transform) + phi halo pack
+int ctx_tune(Ctx&, const char* knob, int value);  // ekpnp_tune's per-context knobs
 void team_detach(Ctx&);  // called by ekpnp_destroy
 bool team_is_group(const Ctx&);  // the context is a member of an in-process ekpnp_group
 void team_timing_reset(Ctx&);    // ekpnp_kernel_timing_enable: forget the exchanges bracketed so far

@@ -146,7 +146,7 @@ __device__ __forceinline__ int fy_row(int r) { return r; }
 // 40 KB of LDS (4 workgroups per CU instead of 2), the two halves of a line paired on one XCD like k_fft_y1024
 __device__ __forceinline__ int fy_row8(int r) { return r ^ ((r >> 3) & 3); }  // stage 0 writes rows 8 t + k for neighbouring t
 template <int SIGN>
-__global__ void __launch_bounds__(256) k_fft_y512c4(double2* __restrict__ spec, const double2* __restrict__ tw, int nxh, long long plane_stride, int npairs) {
+__global__ void __launch_bounds__(256) k_fft_y512c4(double2* __restrict__ spec, const double2* __restrict__ tw, int nxh, long long plane_stride, int npairs, int group0, int groups) {
   constexpr int N = 512, COLS = 4;
   extern __shared__ double2 fy_lds[];
   double2* buf = fy_lds;            // [512 rows][4 columns]
@@ -154,8 +154,7 @@ __global__ void __launch_bounds__(256) k_fft_y512c4(double2* __restrict__ spec, 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int pair = (slot >> 1) * 8 + xcd, half = slot & 1;
   if (pair >= npairs) return;  // uniform over the workgroup
-  const int groups = nxh >> 3;
-  const int plane = pair / groups, group = pair - plane * groups;
+  const int plane = pair / groups, group = group0 + pair - plane * groups;  // groups [group0, group0 + groups) of every plane
   const int c = threadIdx.x & 3, t = threadIdx.x >> 2;  // column, butterfly 0..63
   double2* base = spec + (long long)plane * plane_stride + (long long)group * 8 + half * COLS + c;
   double2 v[8];
@@ -195,7 +194,7 @@ __global__ void __launch_bounds__(256) k_fft_y512c4(double2* __restrict__ spec, 
 // Workgroup -> (plane, 8-column group, half): workgroups are dealt round-robin to the 8 XCDs (bid % 8), and the two
 // halves of one 128-byte line group are consecutive slots of ONE XCD, so the second one finds the lines in that L2.
 template <int SIGN>
-__global__ void __launch_bounds__(256) k_fft_y1024(double2* __restrict__ spec, const double2* __restrict__ tw, int nxh, long long plane_stride, int npairs) {
+__global__ void __launch_bounds__(256) k_fft_y1024(double2* __restrict__ spec, const double2* __restrict__ tw, int nxh, long long plane_stride, int npairs, int group0, int groups) {
   constexpr int N = 1024, COLS = 4;
   extern __shared__ double2 fy_lds[];
   double2* buf = fy_lds;            // [1024 rows][4 columns]
@@ -203,8 +202,7 @@ __global__ void __launch_bounds__(256) k_fft_y1024(double2* __restrict__ spec, c
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int pair = (slot >> 1) * 8 + xcd, half = slot & 1;
   if (pair >= npairs) return;  // uniform over the workgroup
-  const int groups = nxh >> 3;
-  const int plane = pair / groups, group = pair - plane * groups;
+  const int plane = pair / groups, group = group0 + pair - plane * groups;  // groups [group0, group0 + groups) of every plane
   const int c = threadIdx.x & 3, t = threadIdx.x >> 2;  // column, butterfly 0..63
   double2* base = spec + (long long)plane * plane_stride + (long long)group * 8 + half * COLS + c;
   double2 v[16];
@@ -299,33 +297,37 @@ inline bool fft_y_prepare(int ny) {
 }
 
 // in place on `nplanes` planes [ny][nxh] of the half spectrum; sign -1: forward, +1: inverse
-inline void fft_y_launch(double2* spec, const double2* tw, int ny, int nxh, int nplanes, int sign, hipStream_t stream) {
+// group0, ngroups: the 8-column groups [group0, group0 + ngroups) of every plane only (a mode block of the slab solve);
+// ngroups < 0: all nxh / 8 of them
+inline void fft_y_launch(double2* spec, const double2* tw, int ny, int nxh, int nplanes, int sign, hipStream_t stream, int group0 = 0, int ngroups = -1) {
   if (nplanes <= 0) return;
+  if (ngroups < 0) { group0 = 0; ngroups = nxh / 8; }
+  if (ngroups == 0) return;
   const long long ps = (long long)ny * nxh;
   if (ny == 512) {
     // EKPNP_FFTY512_COLS=8: the 8-column kernel of round 2 (the A/B partner)
     static const bool cols8 = std::getenv("EKPNP_FFTY512_COLS") != nullptr && std::atoi(std::getenv("EKPNP_FFTY512_COLS")) == 8;
-    if (cols8) {
+    if (cols8 && group0 == 0 && ngroups == nxh / 8) {
       const dim3 grid(nxh / 8, nplanes);
       if (sign < 0)
         hipLaunchKernelGGL(k_fft_y512<-1>, grid, dim3(512), fy_lds_bytes(512, 8), stream, spec, tw, nxh, ps);
       else
         hipLaunchKernelGGL(k_fft_y512<1>, grid, dim3(512), fy_lds_bytes(512, 8), stream, spec, tw, nxh, ps);
     } else {
-      const int npairs = nplanes * (nxh / 8);
+      const int npairs = nplanes * ngroups;
       const unsigned blocks = (unsigned)((npairs + 7) / 8) * 8 * 2;
       if (sign < 0)
-        hipLaunchKernelGGL(k_fft_y512c4<-1>, dim3(blocks), dim3(256), fy_lds_bytes(512, 4), stream, spec, tw, nxh, ps, npairs);
+        hipLaunchKernelGGL(k_fft_y512c4<-1>, dim3(blocks), dim3(256), fy_lds_bytes(512, 4), stream, spec, tw, nxh, ps, npairs, group0, ngroups);
       else
-        hipLaunchKernelGGL(k_fft_y512c4<1>, dim3(blocks), dim3(256), fy_lds_bytes(512, 4), stream, spec, tw, nxh, ps, npairs);
+        hipLaunchKernelGGL(k_fft_y512c4<1>, dim3(blocks), dim3(256), fy_lds_bytes(512, 4), stream, spec, tw, nxh, ps, npairs, group0, ngroups);
     }
   } else {
-    const int npairs = nplanes * (nxh / 8);
+    const int npairs = nplanes * ngroups;
     const unsigned blocks = (unsigned)((npairs + 7) / 8) * 8 * 2;
     if (sign < 0)
-      hipLaunchKernelGGL(k_fft_y1024<-1>, dim3(blocks), dim3(256), fy_lds_bytes(1024, 4), stream, spec, tw, nxh, ps, npairs);
+      hipLaunchKernelGGL(k_fft_y1024<-1>, dim3(blocks), dim3(256), fy_lds_bytes(1024, 4), stream, spec, tw, nxh, ps, npairs, group0, ngroups);
     else
-      hipLaunchKernelGGL(k_fft_y1024<1>, dim3(blocks), dim3(256), fy_lds_bytes(1024, 4), stream, spec, tw, nxh, ps, npairs);
+      hipLaunchKernelGGL(k_fft_y1024<1>, dim3(blocks), dim3(256), fy_lds_bytes(1024, 4), stream, spec, tw, nxh, ps, npairs, group0, ngroups);
   }
 }
 

@@ -51,6 +51,32 @@ int plane_fft_setup(Ctx& c) {
   return EKPNP_OK;
 }
 
+// The transforms in pieces, for the slab solve with mode blocks (own passes only; with rocFFT plans the 2-D transform is one
+// call, issued with the first / last piece): forward = rows of all planes, then the columns of block k; inverse = the columns
+// of block k, then the rows of all planes.
+int plane_fft_forward_rows(Ctx& c) {
+  if (!c.own_fft) return plane_fft_forward(c);
+  fft_x_forward(c.fft_in(), reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.p.nx, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
+  note_launch(c, "k_fft_x_r2c");
+  return EKPNP_OK;
+}
+void plane_fft_forward_columns(Ctx& c, const ModeBlock& b) {
+  if (!c.own_fft) return;
+  fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw + c.p.nx, c.p.ny, c.nxh, c.fft_nz, -1, c.stream, b.x0 / 8, b.bw / 8);
+  note_launch(c, "k_fft_y<-1>");
+}
+void plane_fft_inverse_columns(Ctx& c, const ModeBlock& b) {
+  if (!c.own_fft) return;
+  fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw + c.p.nx, c.p.ny, c.nxh, c.fft_nz, +1, c.stream, b.x0 / 8, b.bw / 8);
+  note_launch(c, "k_fft_y<1>");
+}
+int plane_fft_inverse_rows(Ctx& c) {
+  if (!c.own_fft) return plane_fft_inverse(c);
+  fft_x_inverse(reinterpret_cast<const double2*>(c.fft_spec()), c.fft_out(), c.fft_tw, c.p.nx, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
+  note_launch(c, "k_fft_x_c2r");
+  return EKPNP_OK;
+}
+
 int plane_fft_forward(Ctx& c) {
   if (c.own_fft) {
     fft_x_forward(c.fft_in(), reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.p.nx, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
@@ -1043,30 +1069,61 @@ static inline bool wide_modes() {
 }
 static inline bool slab_read_once(const Ctx& c) { return c.tri_partition > 0 && c.tri_lds_ok && c.nxh % 8 == 0 && c.slab_m >= 1 && c.slab_m <= 512; }
 
-void launch_slab_thomas_local(Ctx& c) {
+// ---- mode blocks of the slab z solve ("edge_chunks", ekpnp_internal.h: Ctx::edge_chunks) --------------------------------
+// The half spectrum's nxh / 8 column groups (8 kx columns = one 128-byte line of every row) are dealt to the blocks as evenly
+// as they go; block k covers kx in [x0, x0 + bw) and owns the piece [4][ny bw] at doubles offset 4 ny x0 of edge_local and
+// [nranks][4][ny bw] at nranks 4 ny x0 of edge_all.  One block (the default) is the layout of rounds 1-4.
+ModeBlock mode_block(const Ctx& c, int k) {
+  const int groups = c.nxh / 8 > 0 && c.nxh % 8 == 0 ? c.nxh / 8 : 1, unit = c.nxh % 8 == 0 ? 8 : c.nxh;
+  const int nb = edge_chunk_count(c);
+  const int g0 = (int)((long long)groups * k / nb), g1 = (int)((long long)groups * (k + 1) / nb);
+  ModeBlock b;
+  b.x0 = g0 * unit;
+  b.bw = (g1 - g0) * unit;
+  b.local_off = (size_t)4 * c.p.ny * b.x0;
+  b.all_off = (size_t)c.nranks * 4 * c.p.ny * b.x0;
+  b.doubles = (size_t)4 * c.p.ny * b.bw;
+  return b;
+}
+int edge_chunk_count(const Ctx& c) {
+  const int groups = c.nxh % 8 == 0 ? c.nxh / 8 : 1;
+  return c.edge_chunks < 1 ? 1 : (c.edge_chunks > groups ? groups : c.edge_chunks);
+}
+static inline PArgs block_args(const Ctx& c, const ModeBlock& b) {
   PArgs a = c.pargs();
-  const int nm = c.p.ny * c.nxh;
+  a.bx0 = b.x0;
+  a.bw = b.bw;
+  return a;
+}
+
+void launch_slab_thomas_local(Ctx& c, int k) {
+  const ModeBlock blk = mode_block(c, k);
+  PArgs a = block_args(c, blk);
+  const int nm = c.p.ny * blk.bw;
+  double* edge = c.edge_local + blk.local_off;
   if (slab_read_once(c)) {
-    hipLaunchKernelGGL(k_slab_edges, dim3((nm + 63) / 64), dim3(64 * EDGE_SEGS), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, c.edge_local);
+    hipLaunchKernelGGL(k_slab_edges, dim3((nm + 63) / 64), dim3(64 * EDGE_SEGS), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, edge);
     note_launch(c, "k_slab_edges");
     return;
   }
-  hipLaunchKernelGGL(k_slab_thomas_local, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, c.edge_local);
+  hipLaunchKernelGGL(k_slab_thomas_local, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.slab_u, edge);
   note_launch(c, "k_slab_thomas_local");
 }
 
-void launch_slab_reduce_correct(Ctx& c) {
-  PArgs a = c.pargs();
-  const int nm = c.p.ny * c.nxh;
-  // the edge buffer of this rank has been gathered and is free again: it takes (g_lo, g_hi)
-  hipLaunchKernelGGL(k_slab_interface, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.edge_all, c.u1um, c.edge_local);
+void launch_slab_reduce_correct(Ctx& c, int k) {
+  const ModeBlock blk = mode_block(c, k);
+  PArgs a = block_args(c, blk);
+  const int nm = c.p.ny * blk.bw;
+  double* bound = c.edge_local + blk.local_off;
+  // this block's piece of the rank's edge buffer has been gathered and is free again: it takes (g_lo, g_hi)
+  hipLaunchKernelGGL(k_slab_interface, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.rank, c.nranks, c.edge_all + blk.all_off, c.u1um, bound);
   note_launch(c, "k_slab_interface");
   if (slab_read_once(c)) {
     const int m = c.slab_m;
     // (launch + name of one instantiation)
 #define SLAB_PART(RR, LL, GROUP, NAME)                                                                                           \
     do {                                                                                                                         \
-        hipLaunchKernelGGL((k_slab_part<RR, LL>), dim3(nm / (GROUP)), dim3(512), (RR) * 8192, c.stream, a, c.slab_row_a, m, c.edge_local); \
+        hipLaunchKernelGGL((k_slab_part<RR, LL>), dim3(nm / (GROUP)), dim3(512), (RR) * 8192, c.stream, a, c.slab_row_a, m, bound); \
         note_launch(c, "k_slab_part<" NAME ">");                                                                                 \
     } while (0)
     // short columns: several modes per wavefront (LANES of the partition solve) where the mode count allows whole workgroups
@@ -1075,13 +1132,13 @@ void launch_slab_reduce_correct(Ctx& c) {
     else if (m <= 256 && wide_modes() && nm % 16 == 0) SLAB_PART(8, 32, 16, "8,32");
     else if (m <= 256) SLAB_PART(4, 64, 8, "4");
     else if (c.tri_wide && nm % 16 == 0) {
-      hipLaunchKernelGGL((k_slab_part<8, 64, 16>), dim3(nm / 16), dim3(1024), 16 * 8192, c.stream, a, c.slab_row_a, m, c.edge_local);
+      hipLaunchKernelGGL((k_slab_part<8, 64, 16>), dim3(nm / 16), dim3(1024), 16 * 8192, c.stream, a, c.slab_row_a, m, bound);
       note_launch(c, "k_slab_part<8,64,16>");
     } else SLAB_PART(8, 64, 8, "8");
 #undef SLAB_PART
     return;
   }
-  hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, c.edge_local, c.slab_w);
+  hipLaunchKernelGGL(k_slab_reduce_correct, dim3((nm + 63) / 64), dim3(64), 0, c.stream, a, c.slab_row_a, c.slab_m, bound, c.slab_w);
   note_launch(c, "k_slab_reduce_correct");
 }
 

@@ -92,6 +92,7 @@ static Rccl* rccl(std::string& err) {
 
 // ---- the team ------------------------------------------------------------------------------------
 enum { X_HALO = 0, X_PHI = 1, X_EDGE = 2, X_KINDS = 3 };
+constexpr int MAX_BLOCKS = 16;  // mode blocks of the EDGE exchange ("edge_chunks"): its ready / done events are per block, index blk * nslabs + slab
 
 struct Team {
   std::vector<ekpnp_ctx*> m;  // the slabs this process drives, ascending rank
@@ -111,7 +112,11 @@ struct Team {
   // transfer on the comm stream and around the compute stream's wait for it
   struct XEv { hipEvent_t xfer_begin, xfer_end, wait_begin, wait_end; };
   std::vector<std::vector<XEv>> xev[X_KINDS];
-  std::vector<size_t> xev_used[X_KINDS];
+  std::vector<size_t> xev_begun[X_KINDS], xev_used[X_KINDS];  // occurrences started / finished since the last reset (several mode blocks of one EDGE exchange are in flight at once)
+  // knobs (environment at creation, ekpnp_tune / ekpnp_group_tune later; the same on every rank)
+  bool inline_x = true;   // EKPNP_INLINE_EXCHANGES: the EDGE and PHI exchanges of an RCCL team on the compute stream itself
+  int comm_cus = 0;       // EKPNP_COMM_CUS: compute units kept free of the slab's own kernels
+  bool comm_strict = false;
   double t = 0.0;
   std::string err;
   // in-process groups (ekpnp_group_*): a verb that failed on one slab has left the others one call behind or ahead -
@@ -176,7 +181,7 @@ static void for_partners(Team& T, int i, int x, Fn&& fn) {
 // the timed events of the next occurrence of exchange x on local slab i (made on first use, reused after a reset)
 static int xev_slot(Team& T, int x, int i, Team::XEv** out) {
   std::vector<Team::XEv>& v = T.xev[x][i];
-  if (T.xev_used[x][i] == v.size()) {
+  if (T.xev_begun[x][i] == v.size()) {
     Team::XEv e{};
     THIP(T, hipEventCreate(&e.xfer_begin));
     THIP(T, hipEventCreate(&e.xfer_end));
@@ -184,7 +189,7 @@ static int xev_slot(Team& T, int x, int i, Team::XEv** out) {
     THIP(T, hipEventCreate(&e.wait_end));
     v.push_back(e);
   }
-  *out = &v[T.xev_used[x][i]];
+  *out = &v[T.xev_begun[x][i]];
   return EKPNP_OK;
 }
 
@@ -193,34 +198,37 @@ static int xev_slot(Team& T, int x, int i, Team::XEv** out) {
 // stream itself (stream order replaces the events); the population halo keeps its comm stream - that is where the overlap
 // is.  Device-copy groups keep the comm stream for all three (their copies write into the partners' buffers, which the
 // events guard).  EKPNP_INLINE_EXCHANGES=0 is the A/B partner.
-static inline bool inline_exchange(const Team& T, int x) {
-  static const bool on = !(std::getenv("EKPNP_INLINE_EXCHANGES") && std::atoi(std::getenv("EKPNP_INLINE_EXCHANGES")) == 0);
-  return on && T.kind == EKPNP_TRANSPORT_RCCL && x != X_HALO;
+// An EDGE exchange in several mode blocks is there to run BESIDE the transforms of the other blocks: always on the comm stream.
+static inline int edge_blocks(Team& T) { return edge_chunk_count(S(T, 0)); }
+static inline bool inline_exchange(Team& T, int x) {
+  return T.inline_x && T.kind == EKPNP_TRANSPORT_RCCL && x != X_HALO && !(x == X_EDGE && edge_blocks(T) > 1);
 }
 
-// start exchange x: everything the slabs have enqueued so far on their compute streams precedes it
-static int exchange_begin(Team& T, int x) {
+// start exchange x (EDGE: of mode block blk): everything the slabs have enqueued so far on their compute streams precedes it
+static int exchange_begin(Team& T, int x, int blk = 0) {
   const int n = (int)T.m.size();
   const bool inl = inline_exchange(T, x);
+  const int eo = blk * n;  // this block's events
   auto xs = [&](int i) { return inl ? S(T, i).stream : T.cs[i]; };  // the stream slab i's part of the exchange runs on
+  std::vector<Team::XEv*> tev((size_t)n, nullptr);
   int rc;
   for (int i = 0; i < n && !inl; ++i) {
     if ((rc = use(T, i))) return rc;
-    THIP(T, hipEventRecord(T.ready[x][i], S(T, i).stream));
+    THIP(T, hipEventRecord(T.ready[x][eo + i], S(T, i).stream));
   }
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
-    if (!inl) THIP(T, hipStreamWaitEvent(T.cs[i], T.ready[x][i], 0));
+    if (!inl) THIP(T, hipStreamWaitEvent(T.cs[i], T.ready[x][eo + i], 0));
     if (T.kind == EKPNP_TRANSPORT_COPY) {  // slab i's copies write into its partners' receive buffers
       hipError_t e = hipSuccess;
-      for_partners(T, i, x, [&](int j) { if (e == hipSuccess) e = hipStreamWaitEvent(T.cs[i], T.ready[x][j], 0); });
+      for_partners(T, i, x, [&](int j) { if (e == hipSuccess) e = hipStreamWaitEvent(T.cs[i], T.ready[x][eo + j], 0); });
       THIP(T, e);
     }
     if (S(T, i).timing) {  // the stream gets here when this slab's (and its partners') buffers are ready
-      Team::XEv* ev = nullptr;
-      if ((rc = xev_slot(T, x, i, &ev))) return rc;
-      if (inl) THIP(T, hipEventRecord(ev->wait_begin, xs(i)));  // an inline exchange holds the compute stream for its whole length
-      THIP(T, hipEventRecord(ev->xfer_begin, xs(i)));
+      if ((rc = xev_slot(T, x, i, &tev[i]))) return rc;
+      T.xev_begun[x][i]++;
+      if (inl) THIP(T, hipEventRecord(tev[i]->wait_begin, xs(i)));  // an inline exchange holds the compute stream for its whole length
+      THIP(T, hipEventRecord(tev[i]->xfer_begin, xs(i)));
     }
   }
   if (T.kind == EKPNP_TRANSPORT_RCCL) {
@@ -230,8 +238,8 @@ static int exchange_begin(Team& T, int x) {
       if ((rc = use(T, i))) { (void)T.nc->GroupEnd(); return rc; }
       ncclResult_t r = ncclSuccess;
       if (x == X_EDGE) {
-        const size_t per = 4 * (size_t)c.p.ny * c.nxh;
-        r = T.nc->AllGather(c.edge_local, c.edge_all, per, ncclDouble, T.comm[i], xs(i));
+        const ModeBlock mb = mode_block(c, blk);
+        r = T.nc->AllGather(c.edge_local + mb.local_off, c.edge_all + mb.all_off, mb.doubles, ncclDouble, T.comm[i], xs(i));
       } else {
         double** b = x == X_HALO ? c.halo : c.phi_halo;
         const size_t cnt = x == X_HALO ? c.halo_doubles : c.plane;
@@ -263,8 +271,9 @@ static int exchange_begin(Team& T, int x) {
       Ctx& c = S(T, i);
       if ((rc = use(T, i))) return rc;
       if (x == X_EDGE) {
-        const size_t per = 4 * (size_t)c.p.ny * c.nxh;
-        for (int j = 0; j < n; ++j) THIP(T, xcopy(S(T, j).edge_all + (size_t)c.rank * per, S(T, j).device, c.edge_local, c.device, per * sizeof(double), T.cs[i]));
+        const ModeBlock mb = mode_block(c, blk);
+        for (int j = 0; j < n; ++j)
+          THIP(T, xcopy(S(T, j).edge_all + mb.all_off + (size_t)c.rank * mb.doubles, S(T, j).device, c.edge_local + mb.local_off, c.device, mb.doubles * sizeof(double), T.cs[i]));
       } else {
         const int up = (i + 1) % n, dn = (i + n - 1) % n;
         Ctx &cu = S(T, up), &cd = S(T, dn);
@@ -277,35 +286,36 @@ static int exchange_begin(Team& T, int x) {
   }
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
-    if (!inl) THIP(T, hipEventRecord(T.done[x][i], T.cs[i]));
-    if (S(T, i).timing && T.xev_used[x][i] < T.xev[x][i].size()) {
-      Team::XEv& ev = T.xev[x][i][T.xev_used[x][i]];
-      THIP(T, hipEventRecord(ev.xfer_end, xs(i)));
-      if (inl) THIP(T, hipEventRecord(ev.wait_end, xs(i)));
+    if (!inl) THIP(T, hipEventRecord(T.done[x][eo + i], T.cs[i]));
+    if (tev[i]) {
+      THIP(T, hipEventRecord(tev[i]->xfer_end, xs(i)));
+      if (inl) THIP(T, hipEventRecord(tev[i]->wait_end, xs(i)));
     }
   }
   return EKPNP_OK;
 }
 
-// what the slabs enqueue on their compute streams from here on sees the exchanged data
-static int exchange_finish(Team& T, int x) {
+// what the slabs enqueue on their compute streams from here on sees the exchanged data (EDGE: of mode block blk; the blocks
+// are finished in the order they were begun)
+static int exchange_finish(Team& T, int x, int blk = 0) {
   const int n = (int)T.m.size();
+  const int eo = blk * n;
   int rc;
   if (inline_exchange(T, x)) {  // already in stream order; only the measurement's bookkeeping is left
     for (int i = 0; i < n; ++i)
-      if (S(T, i).timing && T.xev_used[x][i] < T.xev[x][i].size()) T.xev_used[x][i]++;
+      if (S(T, i).timing && T.xev_used[x][i] < T.xev_begun[x][i]) T.xev_used[x][i]++;
     return EKPNP_OK;
   }
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
     // measurement: the time the compute stream spends between these two events is the time it had nothing to do but
     // wait for the exchange (0 when the transfer was hidden behind what the stream ran meanwhile)
-    const bool timed = S(T, i).timing && T.xev_used[x][i] < T.xev[x][i].size();
+    const bool timed = S(T, i).timing && T.xev_used[x][i] < T.xev_begun[x][i];
     if (timed) THIP(T, hipEventRecord(T.xev[x][i][T.xev_used[x][i]].wait_begin, S(T, i).stream));
-    THIP(T, hipStreamWaitEvent(S(T, i).stream, T.done[x][i], 0));
+    THIP(T, hipStreamWaitEvent(S(T, i).stream, T.done[x][eo + i], 0));
     if (T.kind == EKPNP_TRANSPORT_COPY) {
       hipError_t e = hipSuccess;
-      for_partners(T, i, x, [&](int j) { if (e == hipSuccess) e = hipStreamWaitEvent(S(T, i).stream, T.done[x][j], 0); });
+      for_partners(T, i, x, [&](int j) { if (e == hipSuccess) e = hipStreamWaitEvent(S(T, i).stream, T.done[x][eo + j], 0); });
       THIP(T, e);
     }
     if (timed) {
@@ -338,19 +348,38 @@ static int team_stream_collide_save(Team& T) {
   return EKPNP_OK;
 }
 
-// fast_Poisson (poisson.cu:75-103) over the slabs
+// fast_Poisson (poisson.cu:75-103) over the slabs.  The z coupling of the reference's 3-D transform (poisson.cu:86-92) is here
+// an all-gather of every slab's edge values (EDGE).  With "edge_chunks" = C > 1 the half spectrum is cut into C blocks of kx
+// columns after the row pass: block k's column pass and edge values run on the compute stream while block k-1's all-gather
+// is on the comm stream, and stage 2 (interface system, z solve, inverse column pass) starts on block 0 as soon as ITS
+// edge values are there, with the later blocks' all-gathers still in flight.  Every mode sees the same operations in the same
+// order whatever C is: phi is bit-identical.
 static int team_fast_poisson(Team& T) {
   const int n = (int)T.m.size();
+  const int nb = edge_blocks(T);
   int rc;
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
-    TSLAB(T, i, ekpnp_poisson_stage1(T.m[i]));
+    TSLAB(T, i, poisson_stage1_begin(S(T, i)));
   }
-  if ((rc = exchange_begin(T, X_EDGE)) || (rc = exchange_finish(T, X_EDGE))) return rc;
+  for (int k = 0; k < nb; ++k) {
+    for (int i = 0; i < n; ++i) {
+      if ((rc = use(T, i))) return rc;
+      TSLAB(T, i, poisson_stage1_block(S(T, i), k));
+      if (k == nb - 1) TSLAB(T, i, poisson_stage1_end(S(T, i)));
+    }
+    if ((rc = exchange_begin(T, X_EDGE, k))) return rc;
+  }
+  for (int k = 0; k < nb; ++k) {
+    if ((rc = exchange_finish(T, X_EDGE, k))) return rc;
+    for (int i = 0; i < n; ++i) {
+      if ((rc = use(T, i))) return rc;
+      TSLAB(T, i, poisson_stage2_block(S(T, i), k));
+    }
+  }
   for (int i = 0; i < n; ++i) {
     if ((rc = use(T, i))) return rc;
-    TSLAB(T, i, ekpnp_poisson_stage2(T.m[i]));
-    TSLAB(T, i, ekpnp_phi_halo_pack(T.m[i]));
+    TSLAB(T, i, poisson_stage2_end(S(T, i)));
   }
   if ((rc = exchange_begin(T, X_PHI)) || (rc = exchange_finish(T, X_PHI))) return rc;
   for (int i = 0; i < n; ++i) {
@@ -523,9 +552,10 @@ static int team_make_streams(Team& T) {
   T.red.assign(n, nullptr);
   T.masked.assign(n, nullptr);
   for (int x = 0; x < X_KINDS; ++x) {
-    T.ready[x].assign(n, nullptr);
-    T.done[x].assign(n, nullptr);
+    T.ready[x].assign((size_t)n * (x == X_EDGE ? MAX_BLOCKS : 1), nullptr);
+    T.done[x].assign(T.ready[x].size(), nullptr);
     T.xev[x].assign(n, {});
+    T.xev_begun[x].assign(n, 0);
     T.xev_used[x].assign(n, 0);
   }
   // EKPNP_COMM_CUS=<n> (A/B knob, default 0): keep n compute units free of the slab's OWN kernels - its compute
@@ -534,8 +564,12 @@ static int team_make_streams(Team& T) {
   // bandwidth-bound and does not miss 3 % of the CUs).  KFD deals the mask bits round-robin over the XCDs, so a
   // multiple of 8 takes the same number of CUs from every XCD and the kernels' bid % 8 XCD maps stay valid.
   // EKPNP_COMM_CUS_STRICT=1 also confines the comm stream to exactly those CUs.
-  static const int comm_cus = std::getenv("EKPNP_COMM_CUS") ? std::atoi(std::getenv("EKPNP_COMM_CUS")) : 0;
-  static const bool comm_strict = std::getenv("EKPNP_COMM_CUS_STRICT") != nullptr && std::atoi(std::getenv("EKPNP_COMM_CUS_STRICT")) != 0;
+  // Both, and EKPNP_INLINE_EXCHANGES, are read when the team is made; ekpnp_tune / ekpnp_group_tune change them on a live one.
+  T.inline_x = !(std::getenv("EKPNP_INLINE_EXCHANGES") && std::atoi(std::getenv("EKPNP_INLINE_EXCHANGES")) == 0);
+  T.comm_cus = std::getenv("EKPNP_COMM_CUS") ? std::atoi(std::getenv("EKPNP_COMM_CUS")) : 0;
+  T.comm_strict = std::getenv("EKPNP_COMM_CUS_STRICT") != nullptr && std::atoi(std::getenv("EKPNP_COMM_CUS_STRICT")) != 0;
+  const int comm_cus = T.comm_cus;
+  const bool comm_strict = T.comm_strict;
   for (int i = 0; i < n; ++i) {
     int rc = use(T, i);
     if (rc) return rc;
@@ -554,10 +588,11 @@ static int team_make_streams(Team& T) {
     // highest priority: a transfer enqueued behind tens of milliseconds of collision kernels must be
     // dispatched as soon as workgroup slots free up, not after the compute queue has drained
     if (!T.cs[i]) THIP(T, hipStreamCreateWithPriority(&T.cs[i], hipStreamNonBlocking, greatest));
-    for (int x = 0; x < X_KINDS; ++x) {
-      THIP(T, hipEventCreateWithFlags(&T.ready[x][i], hipEventDisableTiming));
-      THIP(T, hipEventCreateWithFlags(&T.done[x][i], hipEventDisableTiming));
-    }
+    for (int x = 0; x < X_KINDS; ++x)
+      for (size_t e = (size_t)i; e < T.ready[x].size(); e += (size_t)n) {  // (EDGE: one pair per mode block)
+        THIP(T, hipEventCreateWithFlags(&T.ready[x][e], hipEventDisableTiming));
+        THIP(T, hipEventCreateWithFlags(&T.done[x][e], hipEventDisableTiming));
+      }
     THIP(T, hipMalloc((void**)&T.red[i], 2 * sizeof(double)));
   }
   return EKPNP_OK;
@@ -582,8 +617,10 @@ static void team_release(Team& T) {
   for (size_t i = 0; i < T.m.size(); ++i) {
     (void)hipSetDevice(S(T, (int)i).device);
     for (int x = 0; x < X_KINDS; ++x) {
-      if (i < T.ready[x].size() && T.ready[x][i]) (void)hipEventDestroy(T.ready[x][i]);
-      if (i < T.done[x].size() && T.done[x][i]) (void)hipEventDestroy(T.done[x][i]);
+      for (size_t e = i; e < T.ready[x].size(); e += T.m.size()) {
+        if (T.ready[x][e]) (void)hipEventDestroy(T.ready[x][e]);
+        if (e < T.done[x].size() && T.done[x][e]) (void)hipEventDestroy(T.done[x][e]);
+      }
       if (i < T.xev[x].size())
         for (Team::XEv& e : T.xev[x][i]) {
           (void)hipEventDestroy(e.xfer_begin);
@@ -605,7 +642,49 @@ static void team_release(Team& T) {
   T.cs.clear();
   T.red.clear();
   T.masked.clear();
-  for (int x = 0; x < X_KINDS; ++x) { T.ready[x].clear(); T.done[x].clear(); T.xev[x].clear(); T.xev_used[x].clear(); }
+  for (int x = 0; x < X_KINDS; ++x) { T.ready[x].clear(); T.done[x].clear(); T.xev[x].clear(); T.xev_begun[x].clear(); T.xev_used[x].clear(); }
+}
+
+// ---- knobs of a live team (ekpnp_tune on an attached slab, ekpnp_group_tune) -------------------------------------------------
+// Every rank of the lattice must make the same calls in the same order (like every other verb): "inline_exchanges" decides
+// on which stream a rank's half of a collective is issued, which is its own business, but a run is only an A/B leg when all
+// ranks agree.  Each returns with the team's streams drained.
+static int team_set_comm_cus(Team& T, int cus) {
+  int rc = team_synchronize(T);
+  if (rc) return rc;
+  for (int i = 0; i < (int)T.m.size(); ++i) {
+    if ((rc = use(T, i))) return rc;
+    Ctx& c = S(T, i);
+    int ncu = 0;
+    THIP(T, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device));
+    const bool reserve = cus > 0 && cus < ncu;
+    hipStream_t fresh = nullptr;
+    if (reserve) {
+      std::vector<uint32_t> comp((size_t)(ncu + 31) / 32, 0u);
+      for (int b = cus; b < ncu; ++b) comp[(size_t)b / 32] |= 1u << (b % 32);
+      THIP(T, hipExtStreamCreateWithCUMask(&fresh, (uint32_t)comp.size(), comp.data()));
+    } else {
+      THIP(T, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    }
+    hipStream_t old_masked = T.masked[i];
+    TSLAB(T, i, ekpnp_set_stream(T.m[i], fresh));  // (destroys the slab's previous stream if that was its own)
+    if (old_masked) (void)hipStreamDestroy(old_masked);
+    T.masked[i] = reserve ? fresh : nullptr;
+    c.own_stream = !reserve;  // a plain stream belongs to the slab from here on, a masked one to the team (team_release)
+  }
+  T.comm_cus = cus;
+  return EKPNP_OK;
+}
+static int team_tune(Team& T, const char* knob, int value) {
+  if (std::strcmp(knob, "inline_exchanges") == 0 && (value == 0 || value == 1)) {
+    const int rc = team_synchronize(T);
+    if (rc) return rc;
+    T.inline_x = value != 0;
+    return EKPNP_OK;
+  }
+  if (std::strcmp(knob, "comm_cus") == 0 && value >= 0 && value <= 64) return team_set_comm_cus(T, value);
+  T.err = std::string("unknown transport knob or bad value: ") + knob + " = " + std::to_string(value);
+  return EKPNP_ERR_INVALID;
 }
 
 // ---- the reference's verbs on ONE attached slab context (one process per GPU) --------------------
@@ -642,6 +721,7 @@ int team_ctx_reduce(Ctx& c, double* value, bool is_max) {
   return lift(c, *T, rc);
 }
 int team_ctx_turns(Ctx& c, int (*fn)(Ctx&, void*), void* arg) { OWN_TEAM(c); return lift(c, *T, team_turns(*T, fn, arg)); }
+int team_ctx_tune(Ctx& c, const char* knob, int value) { OWN_TEAM(c); return lift(c, *T, team_tune(*T, knob, value)); }
 
 bool team_is_group(const Ctx& c) { return c.team && c.team->group; }
 
@@ -649,7 +729,7 @@ void team_timing_reset(Ctx& c) {
   if (!c.team) return;
   Team& T = *c.team;
   for (int x = 0; x < X_KINDS; ++x)
-    if ((size_t)c.team_slot < T.xev_used[x].size()) T.xev_used[x][c.team_slot] = 0;
+    if ((size_t)c.team_slot < T.xev_used[x].size()) T.xev_used[x][c.team_slot] = T.xev_begun[x][c.team_slot] = 0;
 }
 
 // sums over the exchanges of kind x bracketed since the last reset, for the slab in slot c.team_slot
@@ -676,10 +756,10 @@ int team_comm_timing_get(Ctx& c, int x, int* n, double* wait_ms, double* transfe
   if (wait_ms) *wait_ms = w;
   if (transfer_ms) *transfer_ms = t;
   if (bytes_sent) {
-    const size_t edge = 4 * (size_t)c.p.ny * c.nxh;
+    const size_t edge = 4 * (size_t)c.p.ny * c.nxh / (size_t)edge_chunk_count(c);  // per exchange: one mode block (their mean size)
     *bytes_sent = sizeof(double) * (x == X_HALO ? 2 * c.halo_doubles : x == X_PHI ? 2 * c.plane : edge);
   }
-  T.xev_used[x][i] = 0;
+  T.xev_used[x][i] = T.xev_begun[x][i] = 0;
   return EKPNP_OK;
 }
 
@@ -946,6 +1026,18 @@ extern "C" int ekpnp_group_init_equilibrium(ekpnp_group* g) { NEEDLIVEGROUP(g); 
 extern "C" int ekpnp_group_stream_collide_save(ekpnp_group* g, double t) { NEEDLIVEGROUP(g); (void)t; return group_fail(T, team_stream_collide_save(T)); }
 extern "C" int ekpnp_group_fast_poisson(ekpnp_group* g) { NEEDLIVEGROUP(g); return group_fail(T, team_fast_poisson(T)); }
 extern "C" int ekpnp_group_step(ekpnp_group* g, int nsteps) { NEEDLIVEGROUP(g); return group_fail(T, team_step(T, nsteps)); }
+
+extern "C" int ekpnp_group_tune(ekpnp_group* g, const char* knob, int value) {
+  NEEDLIVEGROUP(g);
+  if (!knob) { T.err = "knob is NULL"; return EKPNP_ERR_INVALID; }
+  if (std::strcmp(knob, "inline_exchanges") == 0 || std::strcmp(knob, "comm_cus") == 0) return group_fail(T, team_tune(T, knob, value));
+  for (size_t i = 0; i < T.m.size(); ++i) {  // a per-slab knob: the same on every slab (an invalid one is refused by the first, nothing changed)
+    int rc = use(T, (int)i);
+    if (rc) return rc;
+    if ((rc = ctx_tune(S(T, (int)i), knob, value))) { T.err = S(T, (int)i).err; return rc; }
+  }
+  return EKPNP_OK;
+}
 
 extern "C" int ekpnp_group_get_time(ekpnp_group* g, double* t) {
   NEEDGROUP(g);

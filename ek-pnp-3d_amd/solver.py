@@ -111,6 +111,7 @@ def load_library():
         "ekpnp_kernel_timing_enable": (i32, [ctx, i32]),
         "ekpnp_kernel_timing_get": (i32, [ctx, C.POINTER(i32), pd, C.POINTER(C.c_int64)]),
         "ekpnp_phase_timing_get": (i32, [ctx, C.POINTER(i32), pd]),
+        "ekpnp_poisson_stage_timing_get": (i32, [ctx, C.POINTER(i32), pd]),
         "ekpnp_device_bytes": (sz, [ctx]),
         "ekpnp_placement_report": (i32, [ctx, C.POINTER(i32), C.POINTER(i32), pd, i32]),
         "ekpnp_graph_state": (i32, [ctx]),
@@ -169,6 +170,7 @@ def load_library():
         "ekpnp_group_stream_collide_save": (i32, [ctx, dbl]),
         "ekpnp_group_fast_poisson": (i32, [ctx]),
         "ekpnp_group_step": (i32, [ctx, i32]),
+        "ekpnp_group_tune": (i32, [ctx, C.c_char_p, i32]),
         "ekpnp_group_get_time": (i32, [ctx, pd]),
         "ekpnp_group_set_time": (i32, [ctx, dbl]),
         "ekpnp_group_current": (i32, [ctx, pd]),
@@ -237,6 +239,7 @@ def rccl_available() -> str:
 
 
 COMM_KINDS = ("halo", "phi", "edge")  # ekpnp_comm_timing_get kinds 0, 1, 2
+STAGE_NAMES = ("stage1", "edge_exchange", "stage2", "phi_exchange", "stage3")  # ekpnp_poisson_stage_timing_get
 
 
 def comm_timing(L, handle, check) -> dict:
@@ -458,6 +461,13 @@ class Solver:
         self._ck(self._L.ekpnp_phase_timing_get(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def poisson_stage_timing_get(self):
+        """Slab contexts: (n solves, {"stage1", "edge_exchange", "stage2", "phi_exchange", "stage3"}: summed ms) of the
+        solves bracketed so far - call BEFORE phase_timing_get, which resets them."""
+        n, ms = C.c_int(), (C.c_double * 5)()
+        self._ck(self._L.ekpnp_poisson_stage_timing_get(self._h, C.byref(n), ms))
+        return n.value, dict(zip(STAGE_NAMES, (float(v) for v in ms)))
+
     def kernel_timing_get(self):
         n, ms, nodes = C.c_int(), C.c_double(), C.c_int64()
         self._ck(self._L.ekpnp_kernel_timing_get(self._h, C.byref(n), C.byref(ms), C.byref(nodes)))
@@ -586,6 +596,10 @@ class Group:
 
     def fast_Poisson(self):
         self._ck(self._L.ekpnp_group_fast_poisson(self._g))
+
+    def tune(self, knob: str, value: int):
+        """ekpnp_tune's slab and transport knobs on every slab of the group"""
+        self._ck(self._L.ekpnp_group_tune(self._g, knob.encode(), int(value)))
 
     def step(self, n: int = 1):
         self._ck(self._L.ekpnp_group_step(self._g, int(n)))

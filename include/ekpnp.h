@@ -245,6 +245,13 @@ int ekpnp_kernel_timing_get(ekpnp_ctx* ctx, int* n_launches, double* total_ms,
 /* While timing is enabled every Poisson solve (all its stages, on slabs from stage 1 to stage 3
  * including the exchanges in between) is bracketed the same way; this returns and resets the sum. */
 int ekpnp_phase_timing_get(ekpnp_ctx* ctx, int* n_solves, double* poisson_ms);
+/* Slab contexts: where the time of those solves went, from four more HIP events inside each (stage_ms[5], summed over the
+ * n_solves bracketed since timing was enabled or ekpnp_phase_timing_get was last called; call this one FIRST, it does not
+ * reset): [0] stage 1 (right-hand side, forward transform, edge values), [1] from the end of stage 1 to the start of stage 2
+ * = the EDGE all-gather as the compute stream saw it, [2] stage 2 (interface system, z solve, inverse transform, phi pack;
+ * with "edge_chunks" > 1 the waits for the later mode blocks fall in here), [3] the PHI exchange, [4] stage 3.  The sum is
+ * ekpnp_phase_timing_get's poisson_ms.  n_solves = 0 on a single context.  (poisson.cu:75-103) */
+int ekpnp_poisson_stage_timing_get(ekpnp_ctx* ctx, int* n_solves, double* stage_ms);
 size_t ekpnp_device_bytes(const ekpnp_ctx* ctx);
 /* Placement search (no reference counterpart).  On lattices that fill only part of the device the speed of the sweep
  * depends on where the population arena lies in HBM (up to 13 % between placements of the same context); when there is
@@ -265,7 +272,22 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
  * 2 = wherever it applies; the two solve the same system in a different elimination order (equal to rounding).
  * "tri_wide": 1 = 16 modes (wavefronts) per workgroup on columns of more than 256 rows (256-byte pieces of every row; 3 %
  * faster in isolation, default 0), same bits.
- * "lazy_efield": see ekpnp_fast_poisson; same bits. */
+ * "lazy_efield": see ekpnp_fast_poisson; same bits.
+ * Slab contexts (same bits either way): "lead_planes" (EKPNP_SLAB_LEAD_PLANES, default 2): planes of the short launch
+ * in front of the interior sweep that lets the exchange kernel in (0: none); "merged_faces" (EKPNP_MERGED_FACES, default 1):
+ * both faces of a slab in one launch.
+ * Slab contexts whose exchanges the library moves (ekpnp_slab_attach_comm; for groups: ekpnp_group_tune) - every rank makes
+ * the same call, each returns with the streams drained:
+ *   "inline_exchanges" (EKPNP_INLINE_EXCHANGES, default 1): the EDGE and PHI exchanges of an RCCL transport are issued on
+ *     the compute stream itself; 0: on the comm stream, with an event hand-over each way.
+ *   "comm_cus" (EKPNP_COMM_CUS, default 0): that many compute units (a multiple of 8: one per XCD) are kept free of the
+ *     slab's own kernels, for the exchange kernel; the compute stream is re-made.
+ *   "edge_chunks" (EKPNP_EDGE_CHUNKS, default 1, at most 16): the slab solve cuts the half spectrum into that many blocks
+ *     of kx columns and pipelines them: column pass and edge values of block k on the compute stream beside the all-gather
+ *     of block k-1 on the comm stream, stage 2 of block k as soon as its edge values are there.  The edge buffers are then
+ *     laid out block by block, which only the library's own transport exchanges: ekpnp_poisson_stage1/2 refuse such a
+ *     context.  phi is bit-identical for every value.
+ * bench.py runs a few steps under each of these after its timed region on N > 1 GPUs (`comm_ab`). */
 int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value);
 /* Every kernel launch of the library is checked: a rejected launch makes the entry point return
  * EKPNP_ERR_HIP with the KERNEL's name in ekpnp_last_error.  With EKPNP_DEBUG_SYNC set in the
@@ -398,6 +420,7 @@ int ekpnp_group_init_equilibrium(ekpnp_group* g);                     /* LBM.cu:
 int ekpnp_group_stream_collide_save(ekpnp_group* g, double t);        /* LBM.cu:465-481 */
 int ekpnp_group_fast_poisson(ekpnp_group* g);                         /* poisson.cu:75-103 */
 int ekpnp_group_step(ekpnp_group* g, int nsteps);                     /* main.cu:189-200 */
+int ekpnp_group_tune(ekpnp_group* g, const char* knob, int value);    /* ekpnp_tune's slab and transport knobs on every slab of the group */
 int ekpnp_group_get_time(ekpnp_group* g, double* t);
 int ekpnp_group_set_time(ekpnp_group* g, double t);
 int ekpnp_group_current(ekpnp_group* g, double* I);                   /* LBM.cu:2674-2710 */

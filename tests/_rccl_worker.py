@@ -14,6 +14,9 @@ os.environ["NCCL_HOSTID"] = f"ekpnp-test-rank{RANK}"  # before librccl is loaded
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 os.environ.setdefault("NCCL_IB_DISABLE", "1")
 
+# ranks sharing one device must not race for its memory in the placement search of ekpnp_create
+os.environ.setdefault("EKPNP_PLACEMENT_TRIES", "1")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -42,7 +45,15 @@ def main():
         s.set_field(k, start[k][s.z0 : s.z0 + s.nz_local])
     s.fast_Poisson()
     s.init_equilibrium()
-    s.step(6)
+    midway = os.environ.get("EKPNP_RCCL_TUNE_MIDWAY", "")  # "knob=value,...": ekpnp_tune on the live transport after half of the steps
+    if midway:
+        s.step(3)
+        for kv in midway.split(","):
+            k, v = kv.split("=")
+            s.tune(k, int(v))
+        s.step(3)
+    else:
+        s.step(6)
     s.synchronize()
     current, umax = s.current(), s.umax()  # all-reduce inside the library
     fields = s.fields()

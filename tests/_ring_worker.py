@@ -5,6 +5,9 @@ recv_hi, wrap-around) and the rank-major all-gather."""
 import os
 import sys
 
+# ranks sharing one device must not race for its memory in the placement search of ekpnp_create
+os.environ.setdefault("EKPNP_PLACEMENT_TRIES", "1")
+
 import torch
 import torch.distributed as dist
 

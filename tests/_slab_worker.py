@@ -11,6 +11,9 @@ if os.environ.get("EKPNP_SLAB_BACKEND", "gloo") == "nccl" and int(os.environ.get
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     os.environ.setdefault("NCCL_IB_DISABLE", "1")
 
+# ranks sharing one device must not race for its memory in the placement search of ekpnp_create
+os.environ.setdefault("EKPNP_PLACEMENT_TRIES", "1")
+
 import torch
 import torch.distributed as dist
 

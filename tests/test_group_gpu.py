@@ -650,3 +650,126 @@ def test_cpp_driver_ends_cleanly_when_one_slab_fails(tmp_path):
                         "--out", str(tmp_path), "--devices", "0,0,0"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
     assert "slab 1" in r.stderr and "kernel k_collide_bulk" in r.stderr, r.stderr[-2000:]
+
+
+# ---- round 5: the EDGE all-gather in mode blocks ("edge_chunks"), the transport's knobs on a live team, stage times ----------
+
+def _fields_bits(run):
+    f = run.fields()
+    return {k: np.ascontiguousarray(v).copy() for k, v in f.items()}
+
+
+@pytest.mark.parametrize("shape,nslabs,in_place", [((48, 6, 24), 3, 0), ((130, 4, 64), 4, 1), ((16, 12, 16), 2, 0), ((512, 512, 24), 3, 0)])
+def test_edge_chunks_give_the_same_bits_and_match_the_oracle(pkg, O, shape, nslabs, in_place):
+    """the z coupling of the slab solve (the all-gather that replaces the z part of poisson.cu:86-92) in
+    pipelined mode blocks.  Every mode goes through the same operations whatever the number of blocks, so ALL fields after a
+    solve and after 5 steps are bit-identical to the one-block run; the one-block run is held against the oracle.
+    Grids: nxh = 32 (4 column groups: 2, 3 and 5 -> 4 blocks), 72 (9 groups, uneven blocks, in place, serial z sweeps of the
+    64-plane channel's 16-plane slabs), 16 (2 groups), and 512 x 512 planes where the library's OWN row / column passes run
+    and the column pass is cut into the blocks as well (264 = 33 groups)."""
+    po = O.default_params(*shape)
+    po.pb_iterations = 6
+    big = shape[0] >= 512
+    p = _mirror(pkg, po)
+    p.in_place = in_place
+    want = None
+    if not big:
+        ref = _oracle_run(O, po, 5)
+    for chunks in (1, 2, 3, 5):
+        with pkg.Group(p, nslabs, devices=[0] * nslabs) as g:
+            g.tune("edge_chunks", chunks)
+            if not big:
+                _drive(O, g, po, ref, 5)  # every chunk count against the oracle too
+            else:
+                g.initialization()
+                g.set_fields(O.perturb_fields(po, g.fields()))
+                g.fast_Poisson()
+                g.init_equilibrium()
+                g.step(3)
+            got = _fields_bits(g)
+        if want is None:
+            want = got
+        else:
+            for k in want:
+                assert np.array_equal(got[k], want[k]), (chunks, k, float(np.abs(got[k] - want[k]).max()))
+    if big:  # the own-transform planes against a single context (same kernels unchunked), which the parity tests hold against the oracle
+        with pkg.Solver(p) as s:
+            s.initialization()
+            s.set_fields(O.perturb_fields(po, s.fields()))
+            s.fast_Poisson()
+            s.init_equilibrium()
+            s.step(3)
+            _check(O, s.fields(), want, where="512 x 512 planes, slabs vs one context")
+
+
+def test_transport_knobs_on_a_live_one_rank_ring(pkg, O):
+    """the knobs one GPU cannot decide are ekpnp_tune knobs of a live context now (bench.py's comm_ab runs
+    a few steps under each after its timed region).  Here: the same lattice stepped under every setting gives the same bits,
+    the stage times add up to the solve, an unknown knob is refused, and a context without a transport refuses the layout
+    that only the library's transport can exchange."""
+    po = O.default_params(48, 6, 24)
+    po.pb_iterations = 8
+    p = _mirror(pkg, po)
+
+    def run(settings):
+        s = pkg.Solver(p, 0, 1, slab=True)
+        try:
+            s.attach_comm(pkg.comm_unique_id())
+            s.initialization()
+            s.set_fields(O.perturb_fields(po, s.fields()))
+            s.fast_Poisson()
+            s.init_equilibrium()
+            s.step(2)
+            for k, v in settings:
+                s.tune(k, v)
+            s.kernel_timing(True)
+            s.step(4)
+            n, st = s.poisson_stage_timing_get()
+            ns, tot = s.phase_timing_get()
+            s.kernel_timing(False)
+            assert n == ns == 4 and set(st) == set(pkg.STAGE_NAMES)
+            assert all(v >= 0.0 for v in st.values()) and abs(sum(st.values()) - tot) <= 1e-3 * tot + 1e-3
+            return _fields_bits(s), s.comm_timing_get()
+        finally:
+            s.close()
+
+    want, comm0 = run([])
+    assert comm0["edge"]["n"] == 4 and comm0["halo"]["n"] == 4 and comm0["phi"]["n"] == 4
+    for settings in ([("inline_exchanges", 0)], [("comm_cus", 8)], [("comm_cus", 8), ("comm_cus", 0)], [("lead_planes", 0)], [("merged_faces", 0)],
+                     [("edge_chunks", 4)], [("inline_exchanges", 0), ("edge_chunks", 2), ("comm_cus", 16), ("lead_planes", 3)]):
+        got, comm = run(settings)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (settings, k)
+        if ("edge_chunks", 4) in settings:
+            assert comm["edge"]["n"] == 16  # four mode blocks per solve, each bracketed
+    s = pkg.Solver(p, 0, 1, slab=True)
+    try:
+        with pytest.raises(pkg.EkpnpError, match="unknown knob or bad value"):
+            s.tune("edge_chunks", 4)  # no transport: the chunked layout has nobody to exchange it
+        s.tune("edge_chunks", 1)
+        s.attach_comm(pkg.comm_unique_id())
+        with pytest.raises(pkg.EkpnpError, match="unknown"):
+            s.tune("no_such_knob", 1)
+        with pytest.raises(pkg.EkpnpError, match="bad value"):
+            s.tune("comm_cus", 1000)
+        s.tune("edge_chunks", 3)
+        with pytest.raises(pkg.EkpnpError, match="edge_chunks"):
+            s.call("poisson_stage1")  # the exported stages are for a caller's transport: one block only
+    finally:
+        s.close()
+
+
+def test_group_tune_and_stage_times(pkg, O):
+    po = O.default_params(70, 5, 32)
+    po.pb_iterations = 5
+    p = _mirror(pkg, po)
+    with pkg.Group(p, 4, devices=[0] * 4) as g:
+        g.initialization()
+        g.init_equilibrium()
+        g.step(1)
+        g.tune("edge_chunks", 2)
+        g.tune("lead_planes", 0)
+        with pytest.raises(pkg.EkpnpError):
+            g.tune("edge_chunks", 99)
+        g.step(2)
+        assert np.isfinite(g.fields()["phi"]).all()

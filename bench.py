@@ -179,6 +179,66 @@ def comm_block(raw, steps: int, halo_bytes_formula: int, per_rank_wait=None) -> 
     return out
 
 
+COMM_AB_LEGS = (  # (label, [(knob, value) ...]) - what ONE GPU cannot decide; defaults in AB_DEFAULTS
+    ("defaults", []),
+    ("inline_exchanges=0", [("inline_exchanges", 0)]),
+    ("comm_cus=8", [("comm_cus", 8)]),
+    ("lead_planes=0", [("lead_planes", 0)]),
+    ("edge_chunks=4", [("edge_chunks", 4)]),
+    ("edge_chunks=4 comm_cus=8", [("edge_chunks", 4), ("comm_cus", 8)]),
+)
+AB_DEFAULTS = {"inline_exchanges": ("EKPNP_INLINE_EXCHANGES", 1), "comm_cus": ("EKPNP_COMM_CUS", 0), "lead_planes": ("EKPNP_SLAB_LEAD_PLANES", 2),
+               "edge_chunks": ("EKPNP_EDGE_CHUNKS", 1)}
+
+
+def ab_baseline() -> dict:
+    """the knob values the timed region ran with: the library's defaults unless the environment says otherwise"""
+    return {k: int(os.environ.get(env, str(dflt))) for k, (env, dflt) in AB_DEFAULTS.items()}
+
+
+def phases_of(dt_s: float, steps: int, k_ms: float, poisson_ms: float, n_solves: int) -> dict:
+    steps = max(1, steps)
+    bulk, pois = k_ms / steps, poisson_ms / max(1, n_solves)
+    return {"collide_bulk": round(bulk, 4), "poisson": round(pois, 4), "rest": round(dt_s / steps * 1e3 - bulk - pois, 4)}
+
+
+def min_max_by_rank(dicts: list) -> dict:
+    """[{key: value} per rank] -> {"min": {...}, "max": {...}} (the spread the slowest rank hides behind max-over-ranks timing)"""
+    keys = list(dicts[0])
+    return {"min": {k: round(min(d[k] for d in dicts), 4) for k in keys}, "max": {k: round(max(d[k] for d in dicts), 4) for k in keys}}
+
+
+def comm_ab_leg(label, knobs, sol, runner, steps, barrier, dist, torch, world):
+    """ONE leg of the after-the-fact knob A/B: `steps` steps of the live context under `knobs` (set through ekpnp_tune on every
+    rank, in the same order), timed like the headline (barrier + sync both sides, max over ranks), with what the compute
+    stream waited for per exchange (max over ranks) and the solve's stage times (max over ranks).  Outside `value`."""
+    for k, v in knobs:
+        sol.tune(k, v)
+    runner.step(2)  # the first steps after a change re-make streams / first-touch the chunked buffers
+    barrier()
+    sol.kernel_timing(True)
+    t0 = time.perf_counter()
+    runner.step(steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    n_launch, k_ms, _ = sol.kernel_timing_get()
+    _, stages = sol.poisson_stage_timing_get()
+    n_solves, poisson_ms = sol.phase_timing_get()
+    raw = sol.comm_timing_get()
+    sol.kernel_timing(False)
+    vec = [dt * 1e3 / steps, k_ms / steps, poisson_ms / max(1, n_solves)] + [raw[k]["wait_ms"] / steps for k in ("halo", "edge", "phi")] \
+        + [stages[k] / max(1, n_solves) for k in ("stage1", "edge_exchange", "stage2", "phi_exchange", "stage3")]
+    if dist is not None:
+        tv = torch.tensor(vec, dtype=torch.float64)
+        dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+        vec = [float(v) for v in tv]
+    names = ("ms_per_step", "collide_bulk_ms", "poisson_ms", "halo_wait_ms", "edge_wait_ms", "phi_wait_ms",
+             "stage1_ms", "edge_exchange_ms", "stage2_ms", "phi_exchange_ms", "stage3_ms")
+    out = {"knob": label, "steps": steps}
+    out.update({n: round(v, 4) for n, v in zip(names, vec)})
+    return out
+
+
 def step_traffic_of(rec: dict):
     """HBM bytes of one steady-state step from a workload's record in profiles/pmc_traffic.json (tools/summarize_profile.py):
     the sum over the step's kernels of launches per step x counter bytes per launch, or None when the record has no such
@@ -283,7 +343,9 @@ def cpu_model() -> str:
 
 
 def _time_oracle(O, p, threads: int, budget_s: float, perturb: bool):
-    """MLUPS of the oracle's full step on `threads` cores, about budget_s seconds of it."""
+    """MLUPS of the oracle's full step on `threads` cores, about budget_s seconds of it: one untimed step, one timed step
+    to size the sample, then k steps - or, when a single step already takes more than half the budget (one core on 128^3),
+    that one timed step IS the sample."""
     o = O.Oracle(p)
     used = O.set_threads(threads)
     o.threads = used
@@ -296,43 +358,54 @@ def _time_oracle(O, p, threads: int, budget_s: float, perturb: bool):
     t0 = time.perf_counter()
     o.step(1)
     per = time.perf_counter() - t0
-    k = max(2, min(500, int(budget_s / max(per, 1e-4))))
-    t0 = time.perf_counter()
-    o.step(k)
-    dt = time.perf_counter() - t0
+    k, dt = 1, per
+    if per <= 0.5 * budget_s:
+        k = max(2, min(500, int(budget_s / max(per, 1e-4))))
+        t0 = time.perf_counter()
+        o.step(k)
+        dt = time.perf_counter() - t0
     n = o.n
     o.close()
     return n * k / dt / 1e6, k, dt, used
 
 
 def cpu_baseline(nl: int, budget_s: float = 20.0):
-    """BASELINE.md §3.  The reference has no CPU path (every compute routine is a __global__
-    kernel), so the number beside the GPU line is the CPU oracle (kind "port": our restatement of
-    the same step, test infrastructure) timed on this box's host cores, after the timed GPU region:
-      * the multi-lattice sample: the bench's physics (four lattices + Poisson) on 128x128x65,
-        all cores - this is `value`;
-      * cfg1 of BASELINE.json (64x64x64, fluid lattice only, body-force channel) on all cores and
-        on ONE core.
-    Bounded to about budget_s seconds in total."""
+    """BASELINE.md §3, to the letter.  The reference has no CPU path (every compute routine is a __global__ kernel), so the
+    number beside the GPU line is the CPU oracle (kind "port": our restatement of the same step, test infrastructure) timed
+    on this box's host cores, after the timed GPU region:
+      * the multi-lattice point: the bench's physics (its lattices + Poisson) on 128^3, on all cores - this is `value` -
+        and on ONE core (x-y uniform start and one timed step there: a step is seconds long, and timing is data-independent);
+      * cfg1 of BASELINE.json (64x64x64, fluid lattice only, body-force channel) on all cores and on ONE core.
+    MLUPS and the achieved-bandwidth estimate B_alg x LUPS for every leg.  Bounded: about budget_s seconds of timed steps."""
     O = G.load_oracle()
     # OMP_NUM_THREADS if set, else this container's CPU share: its cgroup quota, or the physical cores of its mask
     if os.environ.get("OMP_NUM_THREADS"):
         cores, cores_source = max(1, int(os.environ["OMP_NUM_THREADS"])), "OMP_NUM_THREADS"
     else:
         cores, cores_source = host_cpu_budget()
+    nlat = nl if nl > 1 else 4  # (a fluid-only bench still reports the multi-lattice point BASELINE.md asks for)
     legs = []
-    shape = (128, 128, 65)
-    p = O.default_params(*shape)
-    p.pb_iterations = 3
-    if nl < 4:
-        p.Ra = 0.0
-    v, k, dt, used = _time_oracle(O, p, cores, 0.5 * budget_s, True)
-    main_leg = {"workload": f"{shape[0]}x{shape[1]}x{shape[2]} D3Q27 x4 lattices + Poisson", "cores": used, "value": round(v, 3), "steps": k, "seconds": round(dt, 2)}
-    legs.append(main_leg)
+    shape = (128, 128, 128)
+
+    def multi(th, perturb, budget):
+        p = O.default_params(*shape)
+        p.pb_iterations = 3 if perturb else 1
+        p.n_lattices = nlat
+        if nlat < 4:
+            p.Ra = 0.0
+        v, k, dt, used = _time_oracle(O, p, th, budget, perturb)
+        leg = {"workload": f"{shape[0]}x{shape[1]}x{shape[2]} D3Q27 x{nlat} lattices + Poisson", "cores": used, "value": round(v, 3), "steps": k,
+               "seconds": round(dt, 2), "achieved_GBps": round(v * 1e6 * b_alg_step(nlat) / 1e9, 2)}
+        legs.append(leg)
+        return leg
+
+    main_leg = multi(cores, True, 0.4 * budget_s)
+    if cores > 1:
+        multi(1, False, 0.1 * budget_s)
     p1 = O.default_params(64, 64, 64)
     p1.n_lattices, p1.chargeinf, p1.Ra, p1.TH, p1.exf, p1.pb_iterations = 1, 0.0, 0.0, 0.0, 1e9, 1
-    for th in (cores, 1):
-        v1, k1, dt1, used1 = _time_oracle(O, p1, th, 0.25 * budget_s, False)
+    for th in ((cores, 1) if cores > 1 else (1,)):
+        v1, k1, dt1, used1 = _time_oracle(O, p1, th, 0.15 * budget_s, False)
         legs.append({"workload": "cfg1: 64x64x64 D3Q27 fluid lattice only (exf = 1e9, no ions)", "cores": used1, "value": round(v1, 3), "steps": k1,
                      "seconds": round(dt1, 2), "achieved_GBps": round(v1 * 1e6 * b_alg_step(1) / 1e9, 2)})
     return {
@@ -340,7 +413,7 @@ def cpu_baseline(nl: int, budget_s: float = 20.0):
         "unit": "MLUPS",
         "cores": main_leg["cores"],
         "kind": "port",
-        "sample": f"{main_leg['workload']}, {k} steps, OpenMP oracle ({dt:.1f} s)",
+        "sample": f"{main_leg['workload']}, {main_leg['steps']} steps, OpenMP oracle ({main_leg['seconds']:.1f} s); one-core and cfg1 legs in `legs`",
         "cpu_model": cpu_model(),
         "threads_available": cores,
         "cores_source": cores_source,
@@ -490,6 +563,8 @@ def main():
                     help="N=1 only: run the multi-rank code path (split calls, comm stream, RCCL exchanges, the ring closing on the same rank)")
     ap.add_argument("--weak", action="store_true", help="the named grid is ONE RANK's slab; the channel is N of them (the 512^3-per-rank runs of rounds 1-2: --workload cfg3 --weak)")
     ap.add_argument("--scale-z", type=int, default=1, metavar="D", help="rehearsal: divide the z extent by D (several ranks sharing one GPU); the line says so")
+    ap.add_argument("--no-comm-ab", action="store_true", help="skip the after-the-fact knob A/B of the library's transport (N>1 and --force-slab lines: `comm_ab`)")
+    ap.add_argument("--comm-ab-steps", type=int, default=10, help="steps per leg of that A/B")
     ap.add_argument("--dry-run", action="store_true", help="check the launch plumbing only: rendezvous, barrier, one JSON line with the workload that WOULD run; no GPU")
     ap.add_argument("--cpu-baseline-only", type=int, default=None, metavar="LATTICES", help="internal: time the CPU oracle and print its JSON (the child of cpu_baseline_in_child)")
     args = ap.parse_args()
@@ -716,6 +791,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     n_launch, k_ms, k_nodes = sol.kernel_timing_get()
+    n_stage_solves, stage_ms = sol.poisson_stage_timing_get() if slab_path else (0, None)  # (before phase_timing_get, which resets)
     n_solves, poisson_ms = sol.phase_timing_get()
     comm = None
     if native:
@@ -728,10 +804,28 @@ def main():
         comm = comm_block(raw, args.steps, 2 * 9 * nl * 8 * nx * ny, waits)
     sol.kernel_timing(False)
 
+    # every rank's own phases (its own clock around the same barriers) and solve stages: rank 0 prints the spread
+    my_phases = phases_of(dt, args.steps, k_ms, poisson_ms, n_solves)
+    my_stages = None if not stage_ms else {k: round(v / max(1, n_stage_solves), 4) for k, v in stage_ms.items()}
+    all_phases, all_stages = [my_phases], [my_stages]
     if dist is not None:
+        all_phases, all_stages = [None] * world, [None] * world
+        dist.all_gather_object(all_phases, my_phases)
+        dist.all_gather_object(all_stages, my_stages)
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # After the timed region, outside `value`: a few steps under each knob that one GPU cannot decide, on the live
+    # contexts (ekpnp_tune), so that ONE multi-GPU run says which default is right on xGMI.  Every rank runs every leg.
+    comm_ab = None
+    if native and not args.no_comm_ab and args.comm_ab_steps > 0:
+        base = ab_baseline()
+        comm_ab = []
+        for label, knobs in COMM_AB_LEGS:
+            comm_ab.append(comm_ab_leg(label, knobs, sol, runner, args.comm_ab_steps, barrier, dist, torch, world))
+            for k, _ in knobs:  # back to what the timed region ran with
+                sol.tune(k, base[k])
 
     rho = sol.get_field("rho")
     finite = bool(np.isfinite(rho).all())
@@ -806,11 +900,7 @@ def main():
                 # HIP events on the context's stream inside the timed region: the collide sweep of the interior
                 # planes, the Poisson solve (on slabs: stage 1 to stage 3, exchanges included), and what is
                 # left of the step (wall planes, halo pack / unpack, dependency gaps)
-                "phases_ms_per_step": {
-                    "collide_bulk": round(k_ms / max(1, args.steps), 4),
-                    "poisson": round(poisson_ms / max(1, n_solves), 4),
-                    "rest": round(dt / args.steps * 1e3 - k_ms / max(1, args.steps) - poisson_ms / max(1, n_solves), 4),
-                },
+                "phases_ms_per_step": phases_of(dt, args.steps, k_ms, poisson_ms, n_solves),
             },
             "roofline": {
                 "kernel": "k_collide_bulk",
@@ -834,6 +924,15 @@ def main():
             out["transport_fallback"] = fell_back
             # the scaling loss, itemised: what the compute stream waited for, what the exchanges took, what they moved
             out["comm"] = comm if comm is not None else {"source": "not measured: the python example transport (examples/host_transport.py) ran, not the library's"}
+            # the spread over the ranks (each rank's own events and clock; rank 0's own values are config.phases_ms_per_step)
+            out["config"]["phases_ms_per_step_by_rank"] = min_max_by_rank(all_phases)
+            if all(st is not None for st in all_stages):
+                # where a solve's time goes on a slab: stage 1 | EDGE all-gather as the compute stream saw it | stage 2 | PHI exchange | stage 3
+                out["config"]["poisson_stages_ms_per_solve_by_rank"] = min_max_by_rank(all_stages)
+            if comm_ab is not None:
+                out["comm_ab"] = {"note": f"after the timed region, outside `value`: {args.comm_ab_steps} steps per leg on the live contexts "
+                                          "(ekpnp_tune on every rank); ms_per_step and the waits are maxima over the ranks; the timed region ran with `baseline`",
+                                  "baseline": ab_baseline(), "legs": comm_ab}
         if world == 1 and not args.no_cpu_baseline:
             runner.close()
             out["cpu_baseline"] = cpu_baseline_in_child(nl)

@@ -807,11 +807,10 @@ __global__ void k_slab_thomas_local(PArgs a, int row_a, int m, const double* __r
 // (it is NOT relative to the kept sum: with charge confined to the planes next to one plate the kept terms of the far
 // edge's p can be smaller than a dropped one; tests/test_group_gpu.py::test_slab_edge_values_with_charge_at_one_plate).  The lowest modes (b -> -2, lambda -> 1) need every row, a mid-range mode a few
 // dozen: on a 512-plane slab the kernel touches ~1/6 of the spectrum instead of all of it.  Workgroup = 64 adjacent
-// modes x EDGE_SEGS segments of the K rows (the longest K of the 64 modes), partial sums combined through LDS.
+// modes x EDGE_SEGS segments of the K rows, partial sums combined through LDS in segment order.
 constexpr int EDGE_SEGS = 16;  // 4 measured first: 0.133 ms on a 512-plane slab, the low modes' 128 dependent rows per thread being the critical path
 __global__ void __launch_bounds__(64 * EDGE_SEGS) k_slab_edges(PArgs a, int row_a, int m, const double* __restrict__ u, double* __restrict__ edge) {
   __shared__ double part[EDGE_SEGS][4][64];
-  __shared__ int kmax_s;
   const int tx = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const long long ms = (long long)a.ny * a.nxh, msl = (long long)a.ny * a.bw;
   const long long jm = (long long)blockIdx.x * 64 + tx;  // mode within the block a.bx0, a.bw; edge: [4][ny bw]
@@ -827,18 +826,14 @@ __global__ void __launch_bounds__(64 * EDGE_SEGS) k_slab_edges(PArgs a, int row_
     K = (nl * (double)m > 45.75) ? (int)(45.75 / nl) + 1 : m;
     if (K > m) K = m;
   }
-  if (threadIdx.x == 0) kmax_s = 0;
-  __syncthreads();
-  if (seg == 0) {  // the 64 modes of the workgroup are the lanes of its first wave
-    int kw = K;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) kw = max(kw, __shfl_xor(kw, o, 64));
-    if (tx == 0) kmax_s = kw;
-  }
-  __syncthreads();
-  const int kmax = kmax_s;
-  const int chunk = (kmax + EDGE_SEGS - 1) / EDGE_SEGS;
-  const int j0 = seg * chunk + 1, j1 = min(j0 + chunk - 1, K);  // this thread's rows j0 .. j1 of 1 .. K (its own K)
+  // The K rows of a mode are dealt to the EDGE_SEGS segments by the mode's OWN K, rounded up to a power of two (so that the
+  // 64 adjacent modes of a wave, whose K differ little, mostly walk the same rows: coalesced) - NOT by the longest K of the
+  // workgroup as in rounds 3-4: the order in which a mode's terms are added must not depend on which other modes happen to
+  // share its workgroup, or the solve's bits would change with the mode blocks ("edge_chunks").
+  int Kc = K;
+  if (K > 1 && K < m) Kc = min(m, 1 << (32 - __clz(K - 1)));
+  const int chunk = (Kc + EDGE_SEGS - 1) / EDGE_SEGS;
+  const int j0 = seg * chunk + 1, j1 = min(j0 + chunk - 1, K);  // this thread's rows j0 .. j1 of 1 .. K
   double p1r = 0.0, p1i = 0.0, pmr = 0.0, pmi = 0.0;
   if (live) {
     const double2* s = a.spec + md + (long long)row_a * ms;

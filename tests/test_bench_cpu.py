@@ -227,3 +227,52 @@ def test_step_traffic_comes_from_the_committed_counter_table():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ('"step_traffic_bytes"', '"step_hbm_GBps"', '"step_roofline_frac"'):
         assert key in src
+
+
+def test_comm_ab_leg_keys_and_restoration():
+    """the N>1 line decides the knobs one GPU cannot decide - a few steps under each after the timed
+    region, through ekpnp_tune on the live context.  Without a GPU: a stand-in context records the calls; the leg must set
+    its knobs first, time `steps` steps between barriers, and report the keys the judge reads."""
+    b = _bench()
+    calls = []
+
+    class Fake:
+        def tune(self, k, v):
+            calls.append(("tune", k, v))
+
+        def step(self, n):
+            calls.append(("step", n))
+
+        def kernel_timing(self, on):
+            calls.append(("timing", on))
+
+        def kernel_timing_get(self):
+            return 10, 390.0, 1 << 27
+
+        def poisson_stage_timing_get(self):
+            return 10, {"stage1": 9.0, "edge_exchange": 4.0, "stage2": 11.0, "phi_exchange": 0.5, "stage3": 0.1}
+
+        def phase_timing_get(self):
+            return 10, 24.6
+
+        def comm_timing_get(self):
+            return {k: {"n": 10, "wait_ms": w, "transfer_ms": 1.0, "bytes_sent": 1} for k, w in (("halo", 0.1), ("edge", 4.0), ("phi", 0.5))}
+
+    f = Fake()
+    leg = b.comm_ab_leg("edge_chunks=4", [("edge_chunks", 4)], f, f, 10, lambda: calls.append(("barrier",)), None, None, 1)
+    assert calls[0] == ("tune", "edge_chunks", 4) and ("step", 10) in calls and calls.count(("barrier",)) == 2
+    assert calls.index(("timing", True)) < calls.index(("step", 10)) < calls.index(("timing", False))
+    for key in ("knob", "steps", "ms_per_step", "collide_bulk_ms", "poisson_ms", "halo_wait_ms", "edge_wait_ms", "phi_wait_ms",
+                "stage1_ms", "edge_exchange_ms", "stage2_ms", "phi_exchange_ms", "stage3_ms"):
+        assert key in leg, key
+    assert leg["knob"] == "edge_chunks=4" and leg["collide_bulk_ms"] == 39.0 and leg["edge_wait_ms"] == 0.4 and leg["stage2_ms"] == 1.1
+    # the legs cover every knob the verdict names, and every knob of a leg has a default to go back to
+    knobs = {k for _, ks in b.COMM_AB_LEGS for k, _ in ks}
+    assert knobs == {"inline_exchanges", "comm_cus", "lead_planes", "edge_chunks"} and knobs <= set(b.AB_DEFAULTS)
+    assert b.COMM_AB_LEGS[0] == ("defaults", [])
+    assert b.ab_baseline() == {"inline_exchanges": 1, "comm_cus": 0, "lead_planes": 2, "edge_chunks": 1}
+    mm = b.min_max_by_rank([{"collide_bulk": 38.7, "poisson": 2.1, "rest": 0.3}, {"collide_bulk": 38.9, "poisson": 2.6, "rest": 0.2}])
+    assert mm == {"min": {"collide_bulk": 38.7, "poisson": 2.1, "rest": 0.2}, "max": {"collide_bulk": 38.9, "poisson": 2.6, "rest": 0.3}}
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"comm_ab"', '"phases_ms_per_step_by_rank"', '"poisson_stages_ms_per_solve_by_rank"'):
+        assert key in src

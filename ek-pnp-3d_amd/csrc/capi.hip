@@ -1244,12 +1244,12 @@ extern "C" int ekpnp_phi_halo_buffer(ekpnp_ctx* ctx, int which, double** dptr, s
 extern "C" int ekpnp_halo_pack(ekpnp_ctx* ctx) {
   NEEDCTX(ctx);
   if (!c.slab) return fail(c, "no halo buffers on a single-slab context");
+  if (c.inplace && c.collide_phase != 1) return fail(c, "in-place slab: ekpnp_halo_pack belongs between the boundary and the interior call");
   if (c.halo_sent) {  // the boundary-plane launches stored their outgoing directions straight into the send buffers
     c.halo_sent = false;
     return EKPNP_OK;
   }
   if (c.inplace) {
-    if (c.collide_phase != 1) return fail(c, "in-place slab: ekpnp_halo_pack belongs between the boundary and the interior call");
     launch_halo_pack_stage(c);
   } else {
     // between the boundary and the interior call the fresh planes are in the NEXT buffer

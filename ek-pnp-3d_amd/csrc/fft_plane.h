@@ -19,9 +19,10 @@
 // Unnormalised in both directions, like cuFFT / rocFFT.  The spectrum row pitch nxh is a multiple of 8 (capi.hip); the
 // padding columns beyond NX/2 are transformed along (never read by anyone).
 //
-// Planes of 512 rows / 512 columns are supported too (256-point row transform, 512-point column transform) but NOT the
-// default there: rocFFT's 2 + 2 kernels on 512 x 512 planes run 0.90 + 0.86 ms, these 0.88 + 0.84 ms
-// (profiles/r03_own_plane_fft_probe.log) - nothing to gain, so cfg3 / cfg4 stay on rocFFT unless EKPNP_OWN_FFT=1.
+// Planes of 512 rows / 512 columns are served too (256-point row transform, 512-point column transform) and are the
+// default there since round 4 (poisson.hip: plane_fft_setup): kernel against kernel the gain over rocFFT's 2 + 2 kernels is
+// small (0.88 + 0.84 against 0.90 + 0.86 ms on 512 x 512 x 512, profiles/r03_own_plane_fft_probe.log), inside the full cfg3
+// step the Poisson phase is 2.12 against 2.25 ms (profiles/r04_ab_own_fft_512.log).  EKPNP_OWN_FFT=0 keeps rocFFT.
 //
 // Header-only so that tools/fft_y_probe.hip times exactly the code the library runs.
 #pragma once

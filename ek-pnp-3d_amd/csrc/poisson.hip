@@ -1068,21 +1068,44 @@ static inline bool slab_read_once(const Ctx& c) { return c.tri_partition > 0 && 
 // The half spectrum's nxh / 8 column groups (8 kx columns = one 128-byte line of every row) are dealt to the blocks as evenly
 // as they go; block k covers kx in [x0, x0 + bw) and owns the piece [4][ny bw] at doubles offset 4 ny x0 of edge_local and
 // [nranks][4][ny bw] at nranks 4 ny x0 of edge_all.  One block (the default) is the layout of rounds 1-4.
+//
+// The z-solve kernel (which instantiation of k_slab_part: how many modes share a workgroup) is chosen from the WHOLE
+// spectrum, never from a block - a block solved by another instantiation would eliminate in another order and change the
+// bits - so blocks are made of units of `gu` column groups such that every block holds whole workgroups of that kernel
+// (ny 8 gu a multiple of its modes per workgroup; gu = 1 on every lattice with ny a multiple of 4).
+static int slab_part_modes(const Ctx& c) {  // modes per workgroup of the k_slab_part instantiation this slab runs
+  const int m = c.slab_m, nm = c.p.ny * c.nxh;
+  if (m <= 128) return wide_modes() && nm % 32 == 0 ? 32 : 8;
+  if (m <= 256) return wide_modes() && nm % 16 == 0 ? 16 : 8;
+  return c.tri_wide && nm % 16 == 0 ? 16 : 8;
+}
+static int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
+static int block_unit_groups(const Ctx& c) {
+  if (c.nxh % 8 != 0) return 1;
+  const int q = (slab_read_once(c) ? slab_part_modes(c) : 8) / 8;
+  return q / gcd_int(q, c.p.ny);
+}
+int edge_chunk_count(const Ctx& c) {
+  if (c.nxh % 8 != 0) return 1;
+  const int gu = block_unit_groups(c), units = (c.nxh / 8 + gu - 1) / gu;
+  return c.edge_chunks < 1 ? 1 : (c.edge_chunks > units ? units : c.edge_chunks);
+}
 ModeBlock mode_block(const Ctx& c, int k) {
-  const int groups = c.nxh / 8 > 0 && c.nxh % 8 == 0 ? c.nxh / 8 : 1, unit = c.nxh % 8 == 0 ? 8 : c.nxh;
-  const int nb = edge_chunk_count(c);
-  const int g0 = (int)((long long)groups * k / nb), g1 = (int)((long long)groups * (k + 1) / nb);
   ModeBlock b;
-  b.x0 = g0 * unit;
-  b.bw = (g1 - g0) * unit;
+  if (c.nxh % 8 != 0) {
+    b.x0 = 0;
+    b.bw = c.nxh;
+  } else {
+    const int groups = c.nxh / 8, gu = block_unit_groups(c), units = (groups + gu - 1) / gu, nb = edge_chunk_count(c);
+    const int u0 = (int)((long long)units * k / nb), u1 = (int)((long long)units * (k + 1) / nb);
+    const int g0 = u0 * gu, g1 = u1 * gu < groups ? u1 * gu : groups;
+    b.x0 = g0 * 8;
+    b.bw = (g1 - g0) * 8;
+  }
   b.local_off = (size_t)4 * c.p.ny * b.x0;
   b.all_off = (size_t)c.nranks * 4 * c.p.ny * b.x0;
   b.doubles = (size_t)4 * c.p.ny * b.bw;
   return b;
-}
-int edge_chunk_count(const Ctx& c) {
-  const int groups = c.nxh % 8 == 0 ? c.nxh / 8 : 1;
-  return c.edge_chunks < 1 ? 1 : (c.edge_chunks > groups ? groups : c.edge_chunks);
 }
 static inline PArgs block_args(const Ctx& c, const ModeBlock& b) {
   PArgs a = c.pargs();
@@ -1122,11 +1145,13 @@ void launch_slab_reduce_correct(Ctx& c, int k) {
         note_launch(c, "k_slab_part<" NAME ">");                                                                                 \
     } while (0)
     // short columns: several modes per wavefront (LANES of the partition solve) where the mode count allows whole workgroups
-    if (m <= 128 && wide_modes() && nm % 32 == 0) SLAB_PART(8, 16, 32, "8,16");
+    // - decided on the whole spectrum (slab_part_modes), the block holds whole workgroups of it by construction (mode_block)
+    const int mc = slab_part_modes(c);
+    if (m <= 128 && mc == 32) SLAB_PART(8, 16, 32, "8,16");
     else if (m <= 128) SLAB_PART(2, 64, 8, "2");
-    else if (m <= 256 && wide_modes() && nm % 16 == 0) SLAB_PART(8, 32, 16, "8,32");
+    else if (m <= 256 && mc == 16) SLAB_PART(8, 32, 16, "8,32");
     else if (m <= 256) SLAB_PART(4, 64, 8, "4");
-    else if (c.tri_wide && nm % 16 == 0) {
+    else if (mc == 16) {
       hipLaunchKernelGGL((k_slab_part<8, 64, 16>), dim3(nm / 16), dim3(1024), 16 * 8192, c.stream, a, c.slab_row_a, m, bound);
       note_launch(c, "k_slab_part<8,64,16>");
     } else SLAB_PART(8, 64, 8, "8");

@@ -599,14 +599,23 @@ static int team_make_streams(Team& T) {
 }
 
 static void team_release(Team& T) {
+  // A collective that failed half-issued has kernels waiting for partners that never come.  With ncclCommAbort they are
+  // aborted first and everything below is safe; without it (an RCCL library that does not export it) nothing may wait for
+  // those streams: the comm streams, the slabs' compute streams' pending work and the communicators are LEFT BEHIND (leaked)
+  // rather than blocking ekpnp_group_destroy / ekpnp_destroy for ever.  Untested on hardware: no RCCL failure
+  // could be provoked on the one-GPU boxes; the ordinary path is what the tests run.
+  const bool stuck = T.comm_broken && !(T.nc && T.nc->CommAbort);
   if (T.comm_broken && T.nc && T.nc->CommAbort) {
-    // a collective failed half-issued: its kernels wait for partners that never come - abort them first (untested on
-    // hardware: no RCCL failure could be provoked on the one-GPU boxes; the ordinary path below is what the tests run)
     for (size_t i = 0; i < T.comm.size(); ++i)
       if (T.comm[i]) (void)T.nc->CommAbort(T.comm[i]);
     T.comm.clear();
   }
-  for (size_t i = 0; i < T.m.size(); ++i) {
+  if (stuck) {
+    std::fprintf(stderr, "ekpnp: an RCCL collective failed and this RCCL library has no ncclCommAbort: %zu communicator(s) and their streams are leaked instead of waited for\n", T.comm.size());
+    T.comm.clear();
+    for (size_t i = 0; i < T.cs.size(); ++i) T.cs[i] = nullptr;  // not synchronised, not destroyed
+  }
+  for (size_t i = 0; i < T.m.size() && !stuck; ++i) {
     (void)hipSetDevice(S(T, (int)i).device);
     if (i < T.cs.size() && T.cs[i]) (void)hipStreamSynchronize(T.cs[i]);
     if (S(T, (int)i).stream) (void)hipStreamSynchronize(S(T, (int)i).stream);
@@ -970,7 +979,8 @@ extern "C" int ekpnp_group_create(const ekpnp_params* p, int nslabs, const int* 
 // the group is running when the caller sees the error), the slabs' per-step state is reset, and the group is POISONED:
 // its fields are from mixed steps, so every further verb answers EKPNP_ERR_INVALID with the first failure, and only
 // ekpnp_group_destroy / _last_error / _size / _transport / _context remain.  Attached ranks (one process per GPU) keep
-// the documented contract: the control plane ends all ranks.
+// the documented contract: the control plane ends all ranks.  The drain is SKIPPED when the failure was an RCCL call inside a
+// collective (comm_broken): its kernels may wait for ever, the communicators are aborted at destroy instead (team_release).
 static int group_fail(Team& T, int rc) {
   if (rc == EKPNP_OK || !T.group) return rc;
   const std::string first = T.err;

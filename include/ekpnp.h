@@ -255,7 +255,7 @@ int ekpnp_poisson_stage_timing_get(ekpnp_ctx* ctx, int* n_solves, double* stage_
 size_t ekpnp_device_bytes(const ekpnp_ctx* ctx);
 /* Placement search (no reference counterpart).  On lattices that fill only part of the device the speed of the sweep
  * depends on where the population arena lies in HBM (up to 13 % between placements of the same context); when there is
- * room, ekpnp_create / ekpnp_create_slab time the real sweep on up to EKPNP_PLACEMENT_TRIES (environment, default 3,
+ * room, ekpnp_create / ekpnp_create_slab time the real sweep on up to EKPNP_PLACEMENT_TRIES (environment, default 5,
  * 1 = off) arenas and keep the fastest.  This reports how many were tried, which one was kept and their sweep times
  * in ms (n_tried == 0: no search - the arena is most of the device, or the lattice is launch-bound). */
 int ekpnp_placement_report(ekpnp_ctx* ctx, int* n_tried, int* chosen, double* sweep_ms, int capacity);
@@ -306,8 +306,15 @@ int ekpnp_halo_buffer(ekpnp_ctx* ctx, int which, double** device_ptr, size_t* n_
 /* Since round 4 neither call copies anything by default: ekpnp_collide_boundary_planes stores the outgoing directions
  * straight into the send buffers (ekpnp_halo_pack then has nothing left to do), and after ekpnp_halo_unpack - which now
  * only says "the receive buffers hold the current halos" - the NEXT ekpnp_collide_boundary_planes pulls straight out of
- * them.  The call sequence is unchanged; the receive buffers must stay untouched between ekpnp_halo_unpack and the next
- * ekpnp_collide_boundary_planes.  EKPNP_HALO_DIRECT=0 at creation restores the copies through the ghost planes. */
+ * them.  The call sequence is unchanged, but two ordering rules come with it for a host that moves the buffers itself:
+ *   receive side: the receive buffers must stay untouched between ekpnp_halo_unpack and the next
+ *     ekpnp_collide_boundary_planes (that launch reads them);
+ *   send side: the send buffers are written by the launch of ekpnp_collide_boundary_planes itself, so a transfer out of them
+ *     must be ordered after THAT launch on the context's stream (an event recorded after ekpnp_halo_pack still is: the
+ *     call sequence keeps it behind the boundary launch), and they must not be read before it.
+ * ekpnp_halo_pack keeps its place in the sequence and its checks (in-place slabs: between the boundary and the interior
+ * call) and launches nothing when the boundary launch has filled the buffers already.  EKPNP_HALO_DIRECT=0 at creation
+ * restores the copies through the ghost planes. */
 int ekpnp_halo_pack(ekpnp_ctx* ctx);    /* post-collision boundary planes -> send buffers */
 int ekpnp_halo_unpack(ekpnp_ctx* ctx);  /* recv buffers -> (what the next pull of the edge planes reads) */
 /* One phi plane each way for Ez (poisson.cu:50-55); same `which` numbering. */
@@ -398,8 +405,11 @@ int ekpnp_comm_timing_get(ekpnp_ctx* ctx, int kind, int* n_exchanges, double* wa
  * nobody waits inside a collective for another process.  The call returns only after every slab's compute and comm
  * stream has drained (no kernel of the group is running when the caller sees the error), and the group is then POISONED:
  * some slabs have taken part in the failed verb and some have not, so every further verb that computes, exchanges or
- * reads device state answers EKPNP_ERR_INVALID with the first failure in ekpnp_group_last_error; ekpnp_group_destroy
- * (always clean), _last_error, _size, _transport and _context remain. */
+ * reads device state answers EKPNP_ERR_INVALID with the first failure in ekpnp_group_last_error; ekpnp_group_destroy,
+ * _last_error, _size, _transport and _context remain.  One exception to "drained": when the failure was an RCCL call inside a
+ * collective, kernels of that collective may be waiting for partners that never come; the streams are then NOT waited for,
+ * the communicators are aborted (ncclCommAbort) by ekpnp_group_destroy, and if the RCCL library has no ncclCommAbort the
+ * destroy leaves those streams and communicators behind (leaked, with a message on stderr) instead of blocking for ever. */
 typedef struct ekpnp_group ekpnp_group;
 int ekpnp_group_create(const ekpnp_params* p, int nslabs, const int* devices, int transport, ekpnp_group** out);
 int ekpnp_group_destroy(ekpnp_group* g);

@@ -726,10 +726,11 @@ def test_transport_knobs_on_a_live_one_rank_ring(pkg, O):
             s.step(4)
             n, st = s.poisson_stage_timing_get()
             ns, tot = s.phase_timing_get()
+            comm = s.comm_timing_get()  # (before timing is switched off: that forgets the exchanges bracketed so far)
             s.kernel_timing(False)
             assert n == ns == 4 and set(st) == set(pkg.STAGE_NAMES)
             assert all(v >= 0.0 for v in st.values()) and abs(sum(st.values()) - tot) <= 1e-3 * tot + 1e-3
-            return _fields_bits(s), s.comm_timing_get()
+            return _fields_bits(s), comm
         finally:
             s.close()
 

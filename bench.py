@@ -635,10 +635,8 @@ def main():
         # ranks sharing one device must not race for its free memory: the placement search of ekpnp_create holds up to two
         # extra population arenas for a moment, and a rank that loses that race would leave its peers in ncclCommInitRank
         os.environ.setdefault("EKPNP_PLACEMENT_TRIES", "1")
-        # ... and keep rocFFT's plans: with the library's own plane transforms (workgroups of 36 - 66 KB of LDS) four processes
-        # time-sliced on ONE device ran 1.6 s per step against 48 ms (profiles/r04_rehearsal_4ranks_knobs.log) - a property of
-        # sharing a device between processes, not of the transforms (one process per device: 0.13 ms per solve FASTER)
-        os.environ.setdefault("EKPNP_OWN_FFT", "0")
+        # (rocFFT's plans instead of the own plane transforms on a shared device: the LIBRARY decides that since round 5, when
+        # the communicator is made - ekpnp_plane_transforms; the line reports it as config.plane_transforms)
     torch.cuda.set_device(local_rank)
     pkg = G.load_package()
 
@@ -896,6 +894,8 @@ def main():
                 "device_bytes": sol.device_bytes(),
                 # arenas the context timed at creation and the one it kept (tried 0: the arena is most of the device - cfg3, cfg5)
                 "placement": sol.placement_report(),
+                # the library's own row / column passes or rocFFT plans; ranks of this lattice on rank 0's device (> 1: a rehearsal)
+                "plane_transforms": sol.plane_transforms(),
                 "finite": finite,
                 # HIP events on the context's stream inside the timed region: the collide sweep of the interior
                 # planes, the Poisson solve (on slabs: stage 1 to stage 3, exchanges included), and what is

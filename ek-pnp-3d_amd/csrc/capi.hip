@@ -287,6 +287,58 @@ static int validate(const ekpnp_params* p, int rank, int nranks, std::string& er
 
 static int placement_search(Ctx& c, size_t pitch, int nbuf);
 
+namespace ekpnp {
+// the rocFFT plans (hipFFT API) of the batched 2-D real transforms over the owned interior planes
+int make_fft_plans(Ctx& c) {
+  if (c.plans) return EKPNP_OK;
+  const ekpnp_params* p = &c.p;
+  int n[2] = {p->ny, p->nx};
+  int rembed[2] = {p->ny, p->nx};      // real planes, dense
+  int cembed[2] = {p->ny, c.nxh};      // half spectrum with the padded row pitch
+  hipfftResult r = hipfftPlanMany(&c.plan_fwd, 2, n, rembed, 1, p->ny * p->nx, cembed, 1, p->ny * c.nxh, HIPFFT_D2Z, c.fft_nz);
+  if (r != HIPFFT_SUCCESS) { c.plan_fwd = 0; c.err = "hipfftPlanMany (D2Z) failed: " + std::to_string((int)r); return EKPNP_ERR_FFT; }
+  c.have_fwd = true;
+  r = hipfftPlanMany(&c.plan_inv, 2, n, cembed, 1, p->ny * c.nxh, rembed, 1, p->ny * p->nx, HIPFFT_Z2D, c.fft_nz);
+  if (r != HIPFFT_SUCCESS) { c.plan_inv = 0; c.err = "hipfftPlanMany (Z2D) failed: " + std::to_string((int)r); return EKPNP_ERR_FFT; }
+  c.have_inv = true;
+  c.plans = true;
+  hipfftSetStream(c.plan_fwd, c.stream);
+  hipfftSetStream(c.plan_inv, c.stream);
+  // the work areas rocFFT allocated for the two plans are device memory held by the solver too
+  size_t ws = 0;
+  if (hipfftGetSize(c.plan_fwd, &ws) == HIPFFT_SUCCESS) c.bytes += ws;
+  ws = 0;
+  if (hipfftGetSize(c.plan_inv, &ws) == HIPFFT_SUCCESS) c.bytes += ws;
+  return EKPNP_OK;
+}
+
+// Several RANKS OF ONE LATTICE on one device (rehearsals and tests on a one-GPU box; slab_team.hip finds out when the
+// communicator is made): the library's own row / column passes are workgroups of 256 threads with 36 - 80 KB of LDS, and
+// beside ANOTHER process's collide sweep - a million small workgroups that refill every wave slot the moment one retires -
+// such a workgroup never finds its four SIMD slots and its LDS free at the same time.  Measured, 4 ranks on one MI355X,
+// 512 x 512 x 32 per rank: stage 1 of the solve (row pass, column pass, edge values; no exchange inside) takes 147 - 239 ms
+// against 0.27 - 0.30 ms with rocFFT's plans, stage 2 100 - 278 against 0.36 - 0.46 ms, and the exchanges then wait for the
+// slowest rank (profiles/r05_shared_device_own_fft_off_on.jsonl; round 4 had only the end-to-end 1.6 s against 48 ms per
+// step).  It is the same starvation the halo-exchange kernel met behind the sweep of its OWN process (DESIGN.md section 7:
+// the lead-in launch); rocFFT's kernels are small workgroups and slip in.  One process per device - the production
+// layout - never runs a transform beside a sweep.  So a context that learns it shares its device keeps rocFFT's plans
+// unless EKPNP_OWN_FFT was set explicitly.
+int prefer_fft_plans_on_a_shared_device(Ctx& c) {
+  if (!c.own_fft || std::getenv("EKPNP_OWN_FFT") != nullptr) return EKPNP_OK;
+  HIPCHK(c, hipStreamSynchronize(c.stream));
+  if (int rc = make_fft_plans(c)) return rc;
+  c.own_fft = false;
+  return EKPNP_OK;
+}
+}  // namespace ekpnp
+
+extern "C" int ekpnp_plane_transforms(const ekpnp_ctx* ctx, int* own_passes, int* ranks_on_device) {
+  if (!ctx) return EKPNP_ERR_INVALID;
+  if (own_passes) *own_passes = ctx->c.own_fft ? 1 : 0;
+  if (ranks_on_device) *ranks_on_device = ctx->c.ranks_on_device;
+  return EKPNP_OK;
+}
+
 // the population buffers inside their one allocation: A0 A1 A2 A3 B0 B1 B2 B3 (buffer-major; EKPNP_POP_ORDER=1, an
 // experiment of round 3: lattice-major A0 B0 A1 B1 ... - no difference, profiles/r03_direction_sweep.log)
 static void carve_arena(Ctx& c, void* base, size_t pitch) {
@@ -462,25 +514,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   // planes of 1024 x 1024 (cfg5) are transformed by the library's own row and column kernels (fft_plane.h: 2 + 2 kernels
   // per solve where rocFFT takes 4 + 4); everything else by rocFFT plans
   if ((rc = plane_fft_setup(c))) return bail(rc);
-  if (!c.own_fft) {
-    int n[2] = {p->ny, p->nx};
-    int rembed[2] = {p->ny, p->nx};      // real planes, dense
-    int cembed[2] = {p->ny, c.nxh};      // half spectrum with the padded row pitch
-    hipfftResult r = hipfftPlanMany(&c.plan_fwd, 2, n, rembed, 1, p->ny * p->nx, cembed, 1, p->ny * c.nxh, HIPFFT_D2Z, c.fft_nz);
-    if (r != HIPFFT_SUCCESS) { c.plan_fwd = 0; c.err = "hipfftPlanMany (D2Z) failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
-    c.have_fwd = true;
-    r = hipfftPlanMany(&c.plan_inv, 2, n, cembed, 1, p->ny * c.nxh, rembed, 1, p->ny * p->nx, HIPFFT_Z2D, c.fft_nz);
-    if (r != HIPFFT_SUCCESS) { c.plan_inv = 0; c.err = "hipfftPlanMany (Z2D) failed: " + std::to_string((int)r); return bail(EKPNP_ERR_FFT); }
-    c.have_inv = true;
-    c.plans = true;
-    hipfftSetStream(c.plan_fwd, c.stream);
-    hipfftSetStream(c.plan_inv, c.stream);
-    // the work areas rocFFT allocated for the two plans are device memory held by the solver too
-    size_t ws = 0;
-    if (hipfftGetSize(c.plan_fwd, &ws) == HIPFFT_SUCCESS) c.bytes += ws;
-    ws = 0;
-    if (hipfftGetSize(c.plan_inv, &ws) == HIPFFT_SUCCESS) c.bytes += ws;
-  }
+  if (!c.own_fft && (rc = make_fft_plans(c))) return bail(rc);
   if ((rc = build_cprime(c))) return bail(rc);
   if (hipStreamSynchronize(c.stream) != hipSuccess || hipGetLastError() != hipSuccess) { c.err = "device initialisation failed"; return bail(EKPNP_ERR_HIP); }
   if (arena && (rc = placement_search(c, pop_pitch, pop_nbuf))) return bail(rc);

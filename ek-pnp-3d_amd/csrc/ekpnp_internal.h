@@ -278,6 +278,7 @@ struct Ctx {
   int graph_cur = -1;              // value of `cur` the graph was captured at
   bool graph_failed = false;       // capture is not possible here: stay eager
   bool own_fft = false;            // the 2-D transforms are the library's own kernels (fft_plane.h), no rocFFT plans
+  int ranks_on_device = 1;         // ranks of this lattice on this context's device, itself included (known once a communicator is attached)
   double2* fft_tw = nullptr;       // their twiddle table exp(-2 pi i k / 1024)
   hipfftHandle plan_fwd = 0, plan_inv = 0;
   bool tri_lds_ok = false;  // this context's device grants the partition z solves their dynamic LDS (tridiag_prepare_device)
@@ -347,6 +348,8 @@ int poisson_stage1_end(Ctx&);            // (measurement mark)
 int poisson_stage2_block(Ctx&, int k);   // interface system + z solve of mode block k (its edge values gathered) + inverse column pass
 int poisson_stage2_end(Ctx&);            // inverse row pass (rocFFT plans: the whole inverse transform) + phi halo pack
 int ctx_tune(Ctx&, const char* knob, int value);  // ekpnp_tune's per-context knobs
+int make_fft_plans(Ctx&);                          // capi.hip: the rocFFT plans of the plane transforms (idempotent)
+int prefer_fft_plans_on_a_shared_device(Ctx&);     // capi.hip: own passes -> rocFFT plans unless EKPNP_OWN_FFT is set (why: see there)
 void team_detach(Ctx&);  // called by ekpnp_destroy
 bool team_is_group(const Ctx&);  // the context is a member of an in-process ekpnp_group
 void team_timing_reset(Ctx&);    // ekpnp_kernel_timing_enable: forget the exchanges bracketed so far

@@ -20,6 +20,7 @@
 //   boundary planes -> pack -> [comm: ring] || interior planes -> wait(done) -> unpack.
 // RCCL is bound lazily (dlopen of librccl.so.1) so that single-GPU hosts never load it.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <cmath>
@@ -815,6 +816,48 @@ extern "C" int ekpnp_rccl_available(void) {
   return EKPNP_ERR_HIP;
 }
 
+// How many ranks of the lattice run on this rank's device?  One all-gather of (host, device) identities over the fresh
+// communicator: the host is the machine's boot id + host name (NCCL_HOSTID, which the one-GPU rehearsals set to make RCCL
+// accept several ranks per device, is deliberately NOT what is compared), the device its PCI bus id.
+static uint64_t fnv1a(const void* data, size_t n, uint64_t h = 1469598103934665603ull) {
+  const unsigned char* b = static_cast<const unsigned char*>(data);
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+static int count_ranks_on_my_device(Team& T, Ctx& c) {
+  c.ranks_on_device = 1;
+  if (c.nranks == 1) return EKPNP_OK;
+  uint64_t me[2] = {0, 0};
+  {
+    char buf[256] = {0};
+    if (gethostname(buf, sizeof buf - 1) == 0) me[0] = fnv1a(buf, std::strlen(buf));
+    if (FILE* f = std::fopen("/proc/sys/kernel/random/boot_id", "r")) {
+      char id[64] = {0};
+      if (std::fgets(id, sizeof id, f)) me[0] = fnv1a(id, std::strlen(id), me[0] ? me[0] : 1469598103934665603ull);
+      std::fclose(f);
+    }
+    char bus[64] = {0};
+    THIP(T, hipDeviceGetPCIBusId(bus, sizeof bus, c.device));
+    me[1] = fnv1a(bus, std::strlen(bus));
+  }
+  hipStream_t st = !T.cs.empty() && T.cs[0] ? T.cs[0] : nullptr;  // (a rank whose stream set-up failed still answers, on the null stream)
+  uint64_t* d_all = nullptr;
+  THIP(T, hipMalloc((void**)&d_all, (size_t)(c.nranks + 1) * sizeof me));
+  std::vector<uint64_t> all((size_t)c.nranks * 2, 0);
+  hipError_t e = hipMemcpyAsync(d_all + (size_t)c.nranks * 2, me, sizeof me, hipMemcpyHostToDevice, st);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) r = T.nc->AllGather(d_all + (size_t)c.nranks * 2, d_all, 2, ncclUint64, T.comm[0], st);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_all);
+  if (r != ncclSuccess) { T.err = std::string("ncclAllGather (device identities): ") + T.nc->GetErrorString(r); return EKPNP_ERR_HIP; }
+  THIP(T, e);
+  int same = 0;
+  for (int k = 0; k < c.nranks; ++k) same += all[(size_t)2 * k] == me[0] && all[(size_t)2 * k + 1] == me[1];
+  c.ranks_on_device = same < 1 ? 1 : same;
+  return EKPNP_OK;
+}
+
 extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
   if (!ctx) return EKPNP_ERR_INVALID;
   Ctx& c = ctx->c;
@@ -847,6 +890,11 @@ extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
       T->comm.clear();
     }
   }
+  // collective as well: every rank that HAS a communicator takes part, also one whose local set-up failed (its peers must return)
+  if (!T->comm.empty() && T->comm[0]) {
+    const int crc = count_ranks_on_my_device(*T, c);
+    if (rc == EKPNP_OK) rc = crc;
+  }
   if (rc) {
     c.err = T->err;
     team_release(*T);
@@ -855,6 +903,7 @@ extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
   }
   c.team = T;
   c.team_slot = 0;
+  if (c.ranks_on_device > 1) return prefer_fft_plans_on_a_shared_device(c);
   return EKPNP_OK;
 }
 

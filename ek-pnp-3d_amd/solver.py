@@ -112,6 +112,7 @@ def load_library():
         "ekpnp_kernel_timing_get": (i32, [ctx, C.POINTER(i32), pd, C.POINTER(C.c_int64)]),
         "ekpnp_phase_timing_get": (i32, [ctx, C.POINTER(i32), pd]),
         "ekpnp_poisson_stage_timing_get": (i32, [ctx, C.POINTER(i32), pd]),
+        "ekpnp_plane_transforms": (i32, [ctx, C.POINTER(i32), C.POINTER(i32)]),
         "ekpnp_device_bytes": (sz, [ctx]),
         "ekpnp_placement_report": (i32, [ctx, C.POINTER(i32), C.POINTER(i32), pd, i32]),
         "ekpnp_graph_state": (i32, [ctx]),
@@ -460,6 +461,13 @@ class Solver:
         n, ms = C.c_int(), C.c_double()
         self._ck(self._L.ekpnp_phase_timing_get(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def plane_transforms(self) -> dict:
+        """{"own_passes": the library's own row / column kernels (else rocFFT plans), "ranks_on_device": ranks of the lattice
+        sharing this context's device (known once a communicator is attached)}"""
+        own, n = C.c_int(), C.c_int()
+        self._ck(self._L.ekpnp_plane_transforms(self._h, C.byref(own), C.byref(n)))
+        return {"own_passes": bool(own.value), "ranks_on_device": n.value}
 
     def poisson_stage_timing_get(self):
         """Slab contexts: (n solves, {"stage1", "edge_exchange", "stage2", "phi_exchange", "stage3"}: summed ms) of the

@@ -372,6 +372,16 @@ int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128);
  * agrees on the result over its control plane BEFORE anybody attaches: a rank that cannot bind RCCL returns from
  * ekpnp_slab_attach_comm before the collective, and its peers would wait in theirs (bench.py does exactly this). */
 int ekpnp_rccl_available(void);
+/* Which plane transforms does this context run (1: the library's own row / column passes, 0: rocFFT plans), and how many
+ * ranks of the lattice share its device (itself included; known once ekpnp_slab_attach_comm has made the communicator, 1
+ * before).  SHARED DEVICES: the own passes are the default on planes of 512 / 1024 x 512 / 1024 nodes, but their workgroups
+ * (256 threads, 36 - 80 KB of LDS) starve beside ANOTHER PROCESS's collide sweep on the same device - 4 ranks on one MI355X:
+ * 147 - 239 ms instead of 0.3 ms for stage 1 of a solve (profiles/r05_shared_device_own_fft_off_on.jsonl).  A slab that
+ * finds other ranks of its lattice on its device at ekpnp_slab_attach_comm therefore switches to rocFFT's plans, unless
+ * EKPNP_OWN_FFT was set explicitly (1: keep the own passes, 0: never use them).  The library cannot see UNRELATED processes
+ * on the device: a host that shares a device by other means sets EKPNP_OWN_FFT=0 itself.  One process per device - the
+ * production layout - is not affected (there the own passes are 0.13 ms per solve faster on cfg3). */
+int ekpnp_plane_transforms(const ekpnp_ctx* ctx, int* own_passes, int* ranks_on_device);
 /* Failure semantics of the collective calls (no reference counterpart: the reference exit()s on any error,
  * LBM.cu:35-53).  Once RCCL is bound and the (small, host-side) team object exists, ekpnp_slab_attach_comm always
  * enters ncclCommInitRank, also on a rank whose stream / event set-up failed, so its peers return; the returns BEFORE

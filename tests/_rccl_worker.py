@@ -58,7 +58,8 @@ def main():
     current, umax = s.current(), s.umax()  # all-reduce inside the library
     fields = s.fields()
     if os.environ.get("EKPNP_RCCL_FIELDS_ONLY") == "1":  # full-width planes: fields and diagnostics only (the text files would be GBs)
-        np.savez(os.path.join(out, f"rank{rank}.npz"), z0=s.z0, current=current, umax=umax, **fields)
+        pt = s.plane_transforms()
+        np.savez(os.path.join(out, f"rank{rank}.npz"), z0=s.z0, current=current, umax=umax, own_passes=pt["own_passes"], ranks_on_device=pt["ranks_on_device"], **fields)
         dist.barrier()
         s.close()
         dist.destroy_process_group()

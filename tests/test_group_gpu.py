@@ -742,7 +742,9 @@ def test_transport_knobs_on_a_live_one_rank_ring(pkg, O):
         for k in want:
             assert np.array_equal(got[k], want[k]), (settings, k)
         if ("edge_chunks", 4) in settings:
-            assert comm["edge"]["n"] == 16  # four mode blocks per solve, each bracketed
+            # four blocks asked for; nxh = 32 is 4 column groups, but ny = 6 and the z-solve kernel of a 22-row slab takes 32 modes
+            # per workgroup: a block must hold whole workgroups (units of 2 groups) -> 2 blocks per solve, each bracketed
+            assert comm["edge"]["n"] == 8
     s = pkg.Solver(p, 0, 1, slab=True)
     try:
         with pytest.raises(pkg.EkpnpError, match="unknown knob or bad value"):

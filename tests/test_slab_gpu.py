@@ -224,10 +224,15 @@ def test_native_rccl_ranks_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_p
         assert np.abs(v[1:-1] - want[k][1:-1]).max() <= 2e-6 * max(1.0, np.abs(want[k]).max()), k
 
 
-def test_native_rccl_two_ranks_full_width_planes(pkg, O, tmp_path):
+@pytest.mark.parametrize("own_fft", [None, "1"])
+def test_native_rccl_two_ranks_full_width_planes(pkg, O, tmp_path, own_fft):
     """Two real RCCL ranks (as above) on planes of cfg3's full width: 512 x 512 x 24, i.e. 8 tiles per row,
     the two-node phi / E kernel, 37.7 MB halo messages per direction and lattice group - against the single
-    context on the same lattice (fields and combined diagnostics)."""
+    context on the same lattice (fields and combined diagnostics).
+    Round 5: the two ranks SHARE the box's device, which the library finds out when the communicator is made
+    (ekpnp_plane_transforms: ranks_on_device == 2) and keeps rocFFT's plans then - the own row / column passes starve beside
+    another process's sweep (include/ekpnp.h) - unless EKPNP_OWN_FFT=1 says otherwise: the second case, which also cuts the
+    own column pass into the 4 mode blocks of the midway tune."""
     shape, nprocs = (512, 512, 24), 2
     p = pkg.default_params(*shape)
     p.pb_iterations = 12
@@ -240,6 +245,9 @@ def test_native_rccl_two_ranks_full_width_planes(pkg, O, tmp_path):
     env = dict(os.environ, EKPNP_SLAB_OUT=str(tmp_path), EKPNP_SLAB_IN_PLACE="0", EKPNP_SLAB_GRID="x".join(map(str, shape)),
                EKPNP_RCCL_FIELDS_ONLY="1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
                EKPNP_RCCL_TUNE_MIDWAY="edge_chunks=4")  # round 5: the last three steps with the column pass and the all-gather in 4 mode blocks
+    env.pop("EKPNP_OWN_FFT", None)
+    if own_fft is not None:
+        env["EKPNP_OWN_FFT"] = own_fft
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nprocs}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rccl_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -251,4 +259,6 @@ def test_native_rccl_two_ranks_full_width_planes(pkg, O, tmp_path):
     for d in parts:
         assert abs(float(d["current"]) - want_current) <= 1e-9 * abs(want_current)
         assert abs(float(d["umax"]) - want_umax) <= 1e-6 * abs(want_umax) + 1e-30
-    _assert_vs_oracle(O, got, _oracle_from(O, po, st, 6), parts)  # 6.3 M nodes x 6 steps on the host cores
+        assert int(d["ranks_on_device"]) == 2 and bool(d["own_passes"]) == (own_fft == "1")
+    if own_fft is None:
+        _assert_vs_oracle(O, got, _oracle_from(O, po, st, 6), parts)  # 6.3 M nodes x 6 steps on the host cores

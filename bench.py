@@ -208,12 +208,36 @@ def min_max_by_rank(dicts: list) -> dict:
     return {"min": {k: round(min(d[k] for d in dicts), 4) for k in keys}, "max": {k: round(max(d[k] for d in dicts), 4) for k in keys}}
 
 
-def comm_ab_leg(label, knobs, sol, runner, steps, barrier, dist, torch, world):
+def comm_ab_leg(label, knobs, sol, runner, steps, barrier, dist, torch, world, base=None):
     """ONE leg of the after-the-fact knob A/B: `steps` steps of the live context under `knobs` (set through ekpnp_tune on every
     rank, in the same order), timed like the headline (barrier + sync both sides, max over ranks), with what the compute
-    stream waited for per exchange (max over ranks) and the solve's stage times (max over ranks).  Outside `value`."""
-    for k, v in knobs:
-        sol.tune(k, v)
+    stream waited for per exchange (max over ranks) and the solve's stage times (max over ranks).  Outside `value`.
+    A knob that one rank cannot set (say, a CU mask its driver refuses) must not cost the headline line: the ranks agree on
+    the outcome of the tune calls over the control plane BEFORE anybody steps, and a refused leg is reported as such."""
+    def agree_failed(failed: bool) -> bool:
+        if dist is None:
+            return failed
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return bool(int(flag.item()))
+
+    def restore():
+        for k, _ in knobs:
+            if base is not None and k in base:
+                try:
+                    sol.tune(k, base[k])
+                except Exception:  # noqa: BLE001
+                    pass
+
+    err = None
+    try:
+        for k, v in knobs:
+            sol.tune(k, v)
+    except Exception as e:  # noqa: BLE001
+        err = str(e)
+    if agree_failed(err is not None):
+        restore()
+        return {"knob": label, "error": err or "refused on another rank"}
     runner.step(2)  # the first steps after a change re-make streams / first-touch the chunked buffers
     barrier()
     sol.kernel_timing(True)
@@ -226,6 +250,7 @@ def comm_ab_leg(label, knobs, sol, runner, steps, barrier, dist, torch, world):
     n_solves, poisson_ms = sol.phase_timing_get()
     raw = sol.comm_timing_get()
     sol.kernel_timing(False)
+    restore()  # back to what the timed region ran with
     vec = [dt * 1e3 / steps, k_ms / steps, poisson_ms / max(1, n_solves)] + [raw[k]["wait_ms"] / steps for k in ("halo", "edge", "phi")] \
         + [stages[k] / max(1, n_solves) for k in ("stage1", "edge_exchange", "stage2", "phi_exchange", "stage3")]
     if dist is not None:
@@ -572,6 +597,11 @@ def main():
         print(json.dumps(cpu_baseline(args.cpu_baseline_only)), flush=True)
         return
 
+    if args.single_device and args.gpus > 1:
+        # several PROCESSES on one device oversubscribe its hardware queues unless each keeps to one (include/ekpnp.h:
+        # ekpnp_plane_transforms; profiles/r05_shared_device_experiments.log).  Read by the HIP runtime when it starts: set here,
+        # before torch is imported, in the launcher (the ranks inherit it) and in the ranks.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -635,8 +665,8 @@ def main():
         # ranks sharing one device must not race for its free memory: the placement search of ekpnp_create holds up to two
         # extra population arenas for a moment, and a rank that loses that race would leave its peers in ncclCommInitRank
         os.environ.setdefault("EKPNP_PLACEMENT_TRIES", "1")
-        # (rocFFT's plans instead of the own plane transforms on a shared device: the LIBRARY decides that since round 5, when
-        # the communicator is made - ekpnp_plane_transforms; the line reports it as config.plane_transforms)
+        # (round 4 also forced rocFFT's plans here; round 5 found the cause - hardware-queue oversubscription, GPU_MAX_HW_QUEUES
+        # above - and the own plane transforms run at full speed on a shared device too)
     torch.cuda.set_device(local_rank)
     pkg = G.load_package()
 
@@ -821,9 +851,7 @@ def main():
         base = ab_baseline()
         comm_ab = []
         for label, knobs in COMM_AB_LEGS:
-            comm_ab.append(comm_ab_leg(label, knobs, sol, runner, args.comm_ab_steps, barrier, dist, torch, world))
-            for k, _ in knobs:  # back to what the timed region ran with
-                sol.tune(k, base[k])
+            comm_ab.append(comm_ab_leg(label, knobs, sol, runner, args.comm_ab_steps, barrier, dist, torch, world, base))
 
     rho = sol.get_field("rho")
     finite = bool(np.isfinite(rho).all())

@@ -312,24 +312,6 @@ int make_fft_plans(Ctx& c) {
   return EKPNP_OK;
 }
 
-// Several RANKS OF ONE LATTICE on one device (rehearsals and tests on a one-GPU box; slab_team.hip finds out when the
-// communicator is made): the library's own row / column passes are workgroups of 256 threads with 36 - 80 KB of LDS, and
-// beside ANOTHER process's collide sweep - a million small workgroups that refill every wave slot the moment one retires -
-// such a workgroup never finds its four SIMD slots and its LDS free at the same time.  Measured, 4 ranks on one MI355X,
-// 512 x 512 x 32 per rank: stage 1 of the solve (row pass, column pass, edge values; no exchange inside) takes 147 - 239 ms
-// against 0.27 - 0.30 ms with rocFFT's plans, stage 2 100 - 278 against 0.36 - 0.46 ms, and the exchanges then wait for the
-// slowest rank (profiles/r05_shared_device_own_fft_off_on.jsonl; round 4 had only the end-to-end 1.6 s against 48 ms per
-// step).  It is the same starvation the halo-exchange kernel met behind the sweep of its OWN process (DESIGN.md section 7:
-// the lead-in launch); rocFFT's kernels are small workgroups and slip in.  One process per device - the production
-// layout - never runs a transform beside a sweep.  So a context that learns it shares its device keeps rocFFT's plans
-// unless EKPNP_OWN_FFT was set explicitly.
-int prefer_fft_plans_on_a_shared_device(Ctx& c) {
-  if (!c.own_fft || std::getenv("EKPNP_OWN_FFT") != nullptr) return EKPNP_OK;
-  HIPCHK(c, hipStreamSynchronize(c.stream));
-  if (int rc = make_fft_plans(c)) return rc;
-  c.own_fft = false;
-  return EKPNP_OK;
-}
 }  // namespace ekpnp
 
 extern "C" int ekpnp_plane_transforms(const ekpnp_ctx* ctx, int* own_passes, int* ranks_on_device) {
@@ -515,6 +497,9 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   // per solve where rocFFT takes 4 + 4); everything else by rocFFT plans
   if ((rc = plane_fft_setup(c))) return bail(rc);
   if (!c.own_fft && (rc = make_fft_plans(c))) return bail(rc);
+  // (experiment of round 5, profiles/r05_shared_device_experiments.log: EKPNP_ALSO_MAKE_PLANS made the unused rocFFT plans
+  // beside the own passes - that alone cured the shared-device slowdown, which is how the HIP runtime's stream -> hardware
+  // queue mapping was found to be the cause, not the transforms; see ekpnp_plane_transforms in include/ekpnp.h)
   if ((rc = build_cprime(c))) return bail(rc);
   if (hipStreamSynchronize(c.stream) != hipSuccess || hipGetLastError() != hipSuccess) { c.err = "device initialisation failed"; return bail(EKPNP_ERR_HIP); }
   if (arena && (rc = placement_search(c, pop_pitch, pop_nbuf))) return bail(rc);

@@ -349,7 +349,6 @@ int poisson_stage2_block(Ctx&, int k);   // interface system + z solve of mode b
 int poisson_stage2_end(Ctx&);            // inverse row pass (rocFFT plans: the whole inverse transform) + phi halo pack
 int ctx_tune(Ctx&, const char* knob, int value);  // ekpnp_tune's per-context knobs
 int make_fft_plans(Ctx&);                          // capi.hip: the rocFFT plans of the plane transforms (idempotent)
-int prefer_fft_plans_on_a_shared_device(Ctx&);     // capi.hip: own passes -> rocFFT plans unless EKPNP_OWN_FFT is set (why: see there)
 void team_detach(Ctx&);  // called by ekpnp_destroy
 bool team_is_group(const Ctx&);  // the context is a member of an in-process ekpnp_group
 void team_timing_reset(Ctx&);    // ekpnp_kernel_timing_enable: forget the exchanges bracketed so far

@@ -903,7 +903,21 @@ extern "C" int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128) {
   }
   c.team = T;
   c.team_slot = 0;
-  if (c.ranks_on_device > 1) return prefer_fft_plans_on_a_shared_device(c);
+  if (c.ranks_on_device > 1 && std::getenv("GPU_MAX_HW_QUEUES") == nullptr) {
+    // Several PROCESSES on one device (rehearsals, tests): each HIP process opens up to 4 hardware queues for its streams plus
+    // one per priority level, RCCL adds its own, and four such processes oversubscribe the device's hardware queue slots - the
+    // scheduler then time-slices QUEUES with a coarse quantum and every small kernel of a step waits tens of milliseconds for
+    // its queue's turn (4 ranks on one MI355X: 0.75 - 1.3 s per step against 43 - 50 ms; the per-stage times of the solve show
+    // the stretch in stage 1 and stage 2, which contain no exchange: profiles/r05_shared_device_experiments.log).
+    // GPU_MAX_HW_QUEUES=1 in the ranks' environment (read by the HIP runtime when it starts) cures it.  The library can only say so.
+    static bool said = false;
+    if (!said) {
+      said = true;
+      std::fprintf(stderr, "ekpnp: %d ranks of this lattice share device %d: set GPU_MAX_HW_QUEUES=1 in the ranks' environment, or the "
+                           "processes oversubscribe the device's hardware queues (steps 10 - 30x slower; include/ekpnp.h: ekpnp_plane_transforms)\n",
+                   c.ranks_on_device, c.device);
+    }
+  }
   return EKPNP_OK;
 }
 

@@ -373,14 +373,18 @@ int ekpnp_slab_attach_comm(ekpnp_ctx* ctx, const void* id128);
  * ekpnp_slab_attach_comm before the collective, and its peers would wait in theirs (bench.py does exactly this). */
 int ekpnp_rccl_available(void);
 /* Which plane transforms does this context run (1: the library's own row / column passes, 0: rocFFT plans), and how many
- * ranks of the lattice share its device (itself included; known once ekpnp_slab_attach_comm has made the communicator, 1
- * before).  SHARED DEVICES: the own passes are the default on planes of 512 / 1024 x 512 / 1024 nodes, but their workgroups
- * (256 threads, 36 - 80 KB of LDS) starve beside ANOTHER PROCESS's collide sweep on the same device - 4 ranks on one MI355X:
- * 147 - 239 ms instead of 0.3 ms for stage 1 of a solve (profiles/r05_shared_device_own_fft_off_on.jsonl).  A slab that
- * finds other ranks of its lattice on its device at ekpnp_slab_attach_comm therefore switches to rocFFT's plans, unless
- * EKPNP_OWN_FFT was set explicitly (1: keep the own passes, 0: never use them).  The library cannot see UNRELATED processes
- * on the device: a host that shares a device by other means sets EKPNP_OWN_FFT=0 itself.  One process per device - the
- * production layout - is not affected (there the own passes are 0.13 ms per solve faster on cfg3). */
+ * ranks of the lattice share its device (itself included; known once ekpnp_slab_attach_comm has made the communicator - an
+ * all-gather of boot id + host name + PCI bus id -, 1 before).
+ * PROCESSES THAT SHARE A DEVICE (rehearsals and tests on a one-GPU box; never the production layout): set
+ * GPU_MAX_HW_QUEUES=1 in their environment (the HIP runtime reads it when it starts).  Each HIP process opens up to 4
+ * hardware queues for its streams, more for its priority streams and RCCL's; four such processes oversubscribe the device's
+ * hardware queue slots, the scheduler time-slices the QUEUES, and every small kernel of a step waits for its queue's turn:
+ * 4 ranks on one MI355X ran 0.75 - 1.3 s per step against 43 - 50 ms, with stage 1 of the slab solve (transforms and edge
+ * values, no exchange inside) at 130 - 356 ms instead of 0.27 ms (profiles/r05_shared_device_experiments.log).  Round 4
+ * had blamed the library's own plane transforms (EKPNP_OWN_FFT=0 also cured it); round 5's experiments show that merely
+ * CREATING the rocFFT plans beside the own passes cures it too - plan creation shifts the runtime's stream -> queue mapping -
+ * and that with GPU_MAX_HW_QUEUES=1 both transforms run at full speed (42.8 / 44.0 ms per step).  The library prints this
+ * advice once when ranks_on_device > 1 and the variable is unset; bench.py --single-device and the test workers set it. */
 int ekpnp_plane_transforms(const ekpnp_ctx* ctx, int* own_passes, int* ranks_on_device);
 /* Failure semantics of the collective calls (no reference counterpart: the reference exit()s on any error,
  * LBM.cu:35-53).  Once RCCL is bound and the (small, host-side) team object exists, ekpnp_slab_attach_comm always

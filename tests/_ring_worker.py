@@ -7,6 +7,8 @@ import sys
 
 # ranks sharing one device must not race for its memory in the placement search of ekpnp_create
 os.environ.setdefault("EKPNP_PLACEMENT_TRIES", "1")
+# ... and must not oversubscribe its hardware queues (include/ekpnp.h: ekpnp_plane_transforms); read when the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 
 import torch
 import torch.distributed as dist

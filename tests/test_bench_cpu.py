@@ -259,9 +259,22 @@ def test_comm_ab_leg_keys_and_restoration():
             return {k: {"n": 10, "wait_ms": w, "transfer_ms": 1.0, "bytes_sent": 1} for k, w in (("halo", 0.1), ("edge", 4.0), ("phi", 0.5))}
 
     f = Fake()
-    leg = b.comm_ab_leg("edge_chunks=4", [("edge_chunks", 4)], f, f, 10, lambda: calls.append(("barrier",)), None, None, 1)
+    leg = b.comm_ab_leg("edge_chunks=4", [("edge_chunks", 4)], f, f, 10, lambda: calls.append(("barrier",)), None, None, 1, {"edge_chunks": 1})
     assert calls[0] == ("tune", "edge_chunks", 4) and ("step", 10) in calls and calls.count(("barrier",)) == 2
+    assert calls[-1] == ("tune", "edge_chunks", 1)  # back to what the timed region ran with
     assert calls.index(("timing", True)) < calls.index(("step", 10)) < calls.index(("timing", False))
+
+    class Refuses(Fake):
+        def tune(self, k, v):
+            calls.append(("tune", k, v))
+            if v == 8:
+                raise RuntimeError("hipExtStreamCreateWithCUMask: refused")
+
+    calls.clear()
+    r = Refuses()
+    bad = b.comm_ab_leg("comm_cus=8", [("comm_cus", 8)], r, r, 10, lambda: calls.append(("barrier",)), None, None, 1, {"comm_cus": 0})
+    assert bad == {"knob": "comm_cus=8", "error": "hipExtStreamCreateWithCUMask: refused"} and not any(c[0] == "step" for c in calls)
+    assert calls[-1] == ("tune", "comm_cus", 0)  # a refused leg costs nothing but itself: no step was taken, the knob is back
     for key in ("knob", "steps", "ms_per_step", "collide_bulk_ms", "poisson_ms", "halo_wait_ms", "edge_wait_ms", "phi_wait_ms",
                 "stage1_ms", "edge_exchange_ms", "stage2_ms", "phi_exchange_ms", "stage3_ms"):
         assert key in leg, key

@@ -224,15 +224,15 @@ def test_native_rccl_ranks_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_p
         assert np.abs(v[1:-1] - want[k][1:-1]).max() <= 2e-6 * max(1.0, np.abs(want[k]).max()), k
 
 
-@pytest.mark.parametrize("own_fft", [None, "1"])
+@pytest.mark.parametrize("own_fft", [None, "0"])
 def test_native_rccl_two_ranks_full_width_planes(pkg, O, tmp_path, own_fft):
     """Two real RCCL ranks (as above) on planes of cfg3's full width: 512 x 512 x 24, i.e. 8 tiles per row,
     the two-node phi / E kernel, 37.7 MB halo messages per direction and lattice group - against the single
     context on the same lattice (fields and combined diagnostics).
     Round 5: the two ranks SHARE the box's device, which the library finds out when the communicator is made
-    (ekpnp_plane_transforms: ranks_on_device == 2) and keeps rocFFT's plans then - the own row / column passes starve beside
-    another process's sweep (include/ekpnp.h) - unless EKPNP_OWN_FFT=1 says otherwise: the second case, which also cuts the
-    own column pass into the 4 mode blocks of the midway tune."""
+    (ekpnp_plane_transforms: ranks_on_device == 2); the workers keep to one hardware queue each (GPU_MAX_HW_QUEUES=1,
+    include/ekpnp.h).  Both plane transforms: the library's own row / column passes (the default on 512-wide planes; the
+    midway tune cuts their column pass into 4 mode blocks) and rocFFT's plans (EKPNP_OWN_FFT=0)."""
     shape, nprocs = (512, 512, 24), 2
     p = pkg.default_params(*shape)
     p.pb_iterations = 12
@@ -259,6 +259,6 @@ def test_native_rccl_two_ranks_full_width_planes(pkg, O, tmp_path, own_fft):
     for d in parts:
         assert abs(float(d["current"]) - want_current) <= 1e-9 * abs(want_current)
         assert abs(float(d["umax"]) - want_umax) <= 1e-6 * abs(want_umax) + 1e-30
-        assert int(d["ranks_on_device"]) == 2 and bool(d["own_passes"]) == (own_fft == "1")
+        assert int(d["ranks_on_device"]) == 2 and bool(d["own_passes"]) == (own_fft is None)
     if own_fft is None:
         _assert_vs_oracle(O, got, _oracle_from(O, po, st, 6), parts)  # 6.3 M nodes x 6 steps on the host cores

@@ -312,19 +312,23 @@ with pkg.Solver(p) as s:
         env = dict(os.environ, **env_extra)
         return subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=300)
 
-    r = run({"EKPNP_INJECT_LAUNCH_FAILURE": "k_pbe_relax"}, tmp_path / "x.npy")
-    assert r.returncode == 0 and "ERR" in r.stdout and "kernel k_pbe_relax" in r.stdout, (r.stdout, r.stderr[-2000:])
-    r = run({"EKPNP_INJECT_LAUNCH_FAILURE": "k_collide_all"}, tmp_path / "x.npy")  # small lattice: plates + bulk in one launch
-    assert "ERR" in r.stdout and "kernel k_collide_all" in r.stdout, (r.stdout, r.stderr[-2000:])
-    r = run({"EKPNP_INJECT_LAUNCH_FAILURE": "k_collide_bulk", "EKPNP_NO_MERGED_WALLS": "1"}, tmp_path / "x.npy")
-    assert "ERR" in r.stdout and "kernel k_collide_bulk" in r.stdout, (r.stdout, r.stderr[-2000:])
+    # (the eleven child processes run four at a time: each is a second of HIP start-up around microseconds of kernels)
+    from concurrent.futures import ThreadPoolExecutor
+
+    cases = [({"EKPNP_INJECT_LAUNCH_FAILURE": "k_pbe_relax"}, "k_pbe_relax"),
+             ({"EKPNP_INJECT_LAUNCH_FAILURE": "k_collide_all"}, "k_collide_all"),  # small lattice: plates + bulk in one launch
+             ({"EKPNP_INJECT_LAUNCH_FAILURE": "k_collide_bulk", "EKPNP_NO_MERGED_WALLS": "1"}, "k_collide_bulk")]
     # the z solve has four kernels; each launch is noted under the name of the kernel that was really launched
     for nz, knob, kernel, wide in (("12", "1", "k_tridiag_pcr64", "1"), ("300", "2", "k_tridiag_part<8>", "1"), ("131", "2", "k_tridiag_part<8,32>", "1"),
                                    ("100", "2", "k_tridiag_part<8,16>", "1"), ("131", "2", "k_tridiag_part<4>", "0"), ("300", "0", "k_tridiag", "1")):
-        r = run({"EKPNP_INJECT_LAUNCH_FAILURE": kernel, "EKPNP_TEST_NZ": nz, "EKPNP_TRI_PARTITION": knob, "EKPNP_TRI_WIDE_MODES": wide}, tmp_path / "x.npy")
-        assert "ERR" in r.stdout and f"kernel {kernel}:" in r.stdout, (kernel, r.stdout, r.stderr[-2000:])
-    a = run({}, tmp_path / "a.npy")
-    b = run({"EKPNP_DEBUG_SYNC": "1"}, tmp_path / "b.npy")
+        cases.append(({"EKPNP_INJECT_LAUNCH_FAILURE": kernel, "EKPNP_TEST_NZ": nz, "EKPNP_TRI_PARTITION": knob, "EKPNP_TRI_WIDE_MODES": wide}, kernel))
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(lambda c: run(c[0], tmp_path / ("x_%d.npy" % cases.index(c))), cases))
+        a, b = pool.map(lambda eo: run(*eo), [({}, tmp_path / "a.npy"), ({"EKPNP_DEBUG_SYNC": "1"}, tmp_path / "b.npy")])
+    for (env_extra, kernel), r in zip(cases, results):
+        assert r.returncode == 0 and "ERR" in r.stdout and f"kernel {kernel}" in r.stdout, (kernel, r.stdout, r.stderr[-2000:])
+        if "tridiag" in kernel:
+            assert f"kernel {kernel}:" in r.stdout, (kernel, r.stdout)
     assert "OK 0" in a.stdout and "OK 1" in b.stdout, (a.stdout, b.stdout, b.stderr[-2000:])
     assert np.array_equal(np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy"))
 

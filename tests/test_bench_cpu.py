@@ -289,3 +289,41 @@ def test_comm_ab_leg_keys_and_restoration():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ('"comm_ab"', '"phases_ms_per_step_by_rank"', '"poisson_stages_ms_per_solve_by_rank"'):
         assert key in src
+
+
+def test_comm_ab_legs_agree_over_two_gloo_ranks(tmp_path):
+    """World size 2 over gloo, launched like the driver launches bench.py: the knob A/B of the N>1 line must never leave one rank
+    stepping alone.  Rank 1 refuses `comm_cus=8`: BOTH ranks report that leg (and the combined one) as refused and take no step
+    for it; the other legs carry the maxima over the ranks; every knob goes back to its baseline."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / "ab.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(EKPNP_AB_OUT=str(out), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_comm_ab_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ranks = json.load(open(out))
+    assert [x["rank"] for x in ranks] == [0, 1]
+    for x in ranks:
+        legs = {l["knob"]: l for l in x["legs"]}
+        assert set(legs) == {"defaults", "inline_exchanges=0", "comm_cus=8", "lead_planes=0", "edge_chunks=4", "edge_chunks=4 comm_cus=8"}
+        assert "error" in legs["comm_cus=8"] and "error" in legs["edge_chunks=4 comm_cus=8"]
+        assert ("refused on another rank" in legs["comm_cus=8"]["error"]) == (x["rank"] == 0)
+        for k in ("defaults", "inline_exchanges=0", "lead_planes=0", "edge_chunks=4"):
+            # maxima over the ranks: rank 1's sweep (200 ms / 10 steps), waits (2 ms / 10) and EDGE stage (4 ms / 10 solves)
+            assert legs[k]["collide_bulk_ms"] == 20.0 and legs[k]["halo_wait_ms"] == 0.2 and legs[k]["edge_exchange_ms"] == 0.4, legs[k]
+        steps = [c for c in x["calls"] if c[0] == "step"]
+        assert len(steps) == 2 * 4  # (2 settling + 10 timed) for the four legs that ran, none for the refused ones
+        tunes = [c for c in x["calls"] if c[0] == "tune"]
+        final = {}
+        for _, k, v in tunes:
+            final[k] = v
+        assert final == {"inline_exchanges": 1, "comm_cus": 0, "lead_planes": 2, "edge_chunks": 1}

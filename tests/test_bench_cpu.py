@@ -215,7 +215,7 @@ def test_step_traffic_comes_from_the_committed_counter_table():
     rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["cfg3"]
     st = rec["step"]
     names = " ".join(e["kernel"] for e in st["kernels"])
-    for k in ("k_collide_bulk<4, true, true>", "k_collide_wall<4, true, true>", "k_fft_x_r2c<512>", "k_fft_x_c2r<512>", "k_fft_y512", "k_tridiag_part<8, 64>"):
+    for k in ("k_collide_bulk<4, true, true>", "k_collide_wall<4, true, true>", "k_fft_x_r2c<512>", "k_fft_x_c2r<512>", "k_fft_y512", "k_tridiag_part<8, 64"):
         assert k in names, k
     tot = b.step_traffic_of(rec)
     assert abs(tot - st["hbm_bytes_per_step"]) < 1.0

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/ekpnp.h"
@@ -58,6 +59,7 @@ int main(int argc, char* argv[]) {
   std::string out = ".";
   double exf = 0.0, uw = 0.0, chargeinf = -1.0, Ra = -1.0, TH = -1.0;
   double converged_tol = 0.0;  // > 0: ekpnp_initialization_converged instead of the reference's fixed 501 Picard sweeps
+  std::vector<std::pair<std::string, int>> tunes;  // --tune knob=value: ekpnp_tune / ekpnp_group_tune right after creation
   for (int i = 1; i < argc; ++i) {
     auto val = [&](const char* name) -> const char* {
       if (std::strcmp(argv[i], name) == 0 && i + 1 < argc) return argv[++i];
@@ -90,11 +92,20 @@ int main(int argc, char* argv[]) {
     else if ((v = val("--Ra"))) Ra = std::atof(v);
     else if ((v = val("--TH"))) TH = std::atof(v);
     else if ((v = val("--converged-init"))) converged_tol = std::atof(v);
+    else if ((v = val("--tune"))) {
+      const char* eq = std::strchr(v, '=');
+      if (!eq || eq == v) { std::fprintf(stderr, "--tune wants knob=value, got %s\n", v); return 2; }
+      tunes.emplace_back(std::string(v, eq), std::atoi(eq + 1));
+    }
     else {
       std::fprintf(stderr,
                    "usage: ekpnp_main [--nx N --ny N --nz N] [--steps N] [--nsave N] [--print-current N] [--read-previous 0|1|2]\n"
                    "                  [--binary-state 0|1] [--gpus N [--transport auto|rccl|copy] [--devices d0,d1,...]]\n"
                    "                  [--lattices 1|3|4] [--exf F --uw U --chargeinf C --Ra R --TH T] [--out DIR] [--converged-init TOL]\n"
+                   "                  [--tune knob=value ...]\n"
+                   "  --tune knob=value: a launch-shape or transport knob of include/ekpnp.h's ekpnp_tune (with --gpus N: on every slab), e.g.\n"
+                   "  edge_chunks=4 (the slab Poisson solve's all-gather in 4 pipelined blocks), lead_planes=0, inline_exchanges=0, comm_cus=8;\n"
+                   "  the results are the same bits under every setting.\n"
                    "  --converged-init TOL: Poisson-Boltzmann start-up with a convergence test and a damping that cannot diverge\n"
                    "  (ekpnp_initialization_converged); the reference's 501 sweeps with PB_omega = 0.05 (LBM.cu:89-106) diverge to NaN on\n"
                    "  channels taller than about 180 planes at the default spacing.\n"
@@ -137,6 +148,10 @@ int main(int argc, char* argv[]) {
   } else {
     int rc = ekpnp_create(&P, &ctx);
     if (rc != EKPNP_OK) return fail("ekpnp_create", rc);
+  }
+  for (const auto& kv : tunes) {
+    const int rc = grp ? ekpnp_group_tune(grp, kv.first.c_str(), kv.second) : ekpnp_tune(ctx, kv.first.c_str(), kv.second);
+    if (rc != EKPNP_OK) return fail(("--tune " + kv.first).c_str(), rc);
   }
   std::printf("HIP information\n");
   if (grp)

@@ -205,7 +205,8 @@ def test_cpp_driver_with_slabs_writes_the_single_gpu_files(pkg, tmp_path):
         pytest.skip("ekpnp_main not built")
     geo = ["--nx", "24", "--ny", "6", "--nz", "32", "--steps", "40", "--nsave", "15", "--print-current", "10"]
     outs = {}
-    for tag, extra in (("one", []), ("four", ["--devices", "0,0,0,0"]), ("rccl1", ["--devices", "0", "--transport", "rccl"])):
+    # (the four-slab run also takes the transport's knobs from the command line: --tune, round 5 - same bits under every setting)
+    for tag, extra in (("one", []), ("four", ["--devices", "0,0,0,0", "--tune", "edge_chunks=2", "--tune", "lead_planes=0"]), ("rccl1", ["--devices", "0", "--transport", "rccl"])):
         d = tmp_path / tag
         d.mkdir()
         r = subprocess.run([exe, *geo, "--out", str(d), "--binary-state", "1", *extra], capture_output=True, text=True, timeout=600)

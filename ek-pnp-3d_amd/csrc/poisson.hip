@@ -1071,8 +1071,8 @@ static inline bool slab_read_once(const Ctx& c) { return c.tri_partition > 0 && 
 //
 // The z-solve kernel (which instantiation of k_slab_part: how many modes share a workgroup) is chosen from the WHOLE
 // spectrum, never from a block - a block solved by another instantiation would eliminate in another order and change the
-// bits - so blocks are made of units of `gu` column groups such that every block holds whole workgroups of that kernel
-// (ny 8 gu a multiple of its modes per workgroup; gu = 1 on every lattice with ny a multiple of 4).
+// bits - so blocks are made of units of `gu` column groups such that every block holds whole workgroups of any of them
+// (ny 8 gu a multiple of 32 modes; gu = 1 on every lattice with ny a multiple of 4), the same units on every rank.
 static int slab_part_modes(const Ctx& c) {  // modes per workgroup of the k_slab_part instantiation this slab runs
   const int m = c.slab_m, nm = c.p.ny * c.nxh;
   if (m <= 128) return wide_modes() && nm % 32 == 0 ? 32 : 8;
@@ -1081,9 +1081,10 @@ static int slab_part_modes(const Ctx& c) {  // modes per workgroup of the k_slab
 }
 static int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
 static int block_unit_groups(const Ctx& c) {
+  // The same on EVERY rank (the blocks are the pieces of a collective): it depends on the lattice only, not on this slab's row
+  // count or knobs - units that hold whole workgroups of the widest instantiation (32 modes) hold whole ones of the others too.
   if (c.nxh % 8 != 0) return 1;
-  const int q = (slab_read_once(c) ? slab_part_modes(c) : 8) / 8;
-  return q / gcd_int(q, c.p.ny);
+  return 4 / gcd_int(4, c.p.ny);
 }
 int edge_chunk_count(const Ctx& c) {
   if (c.nxh % 8 != 0) return 1;

@@ -703,6 +703,43 @@ def test_edge_chunks_give_the_same_bits_and_match_the_oracle(pkg, O, shape, nsla
             _check(O, s.fields(), want, where="512 x 512 planes, slabs vs one context")
 
 
+def test_edge_chunks_when_the_slabs_run_different_z_solve_kernels(pkg, O):
+    """The mode blocks are the pieces of a COLLECTIVE: their boundaries must be the same on every rank, whatever z-solve kernel a
+    rank runs.  48 x 6 x 388 in three slabs gives unknown-row counts of 128, 129, 129: slab 0 runs k_slab_part<8,16> (32 modes
+    per workgroup), the others <8,32> (16 modes) - with block units derived from the slab's own kernel the ranks disagreed
+    about the blocks (units of 2 and of 1 column groups at ny = 6).  Bit-identical fields for 1, 2, 3 blocks, and against the
+    oracle (uniform start + perturbation: the reference's Picard start-up diverges on a channel this tall)."""
+    po = O.default_params(48, 6, 388)
+    orc = O.Oracle(po)
+    try:
+        orc.gpu_initialization()
+        start = O.perturb_fields(po, orc.fields())
+        orc.set_fields(start)
+        orc.fast_poisson()
+        orc.init_equilibrium()
+        orc.step(4)
+        ref = orc.fields()
+    finally:
+        orc.close()
+    p = _mirror(pkg, po)
+    want = None
+    for chunks in (1, 2, 3):
+        with pkg.Group(p, 3, devices=[0, 0, 0]) as g:
+            assert [g.slab_extent(i)[1] for i in range(3)] == [129, 129, 130]
+            g.tune("edge_chunks", chunks)
+            g.set_fields(start)
+            g.fast_Poisson()
+            g.init_equilibrium()
+            g.step(4)
+            got = _fields_bits(g)
+        _check(O, got, ref, where=f"{chunks} blocks")
+        if want is None:
+            want = got
+        else:
+            for k in want:
+                assert np.array_equal(got[k], want[k]), (chunks, k)
+
+
 def test_transport_knobs_on_a_live_one_rank_ring(pkg, O):
     """the knobs one GPU cannot decide are ekpnp_tune knobs of a live context now (bench.py's comm_ab runs
     a few steps under each after its timed region).  Here: the same lattice stepped under every setting gives the same bits,

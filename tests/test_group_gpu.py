@@ -713,12 +713,16 @@ def test_edge_chunks_when_the_slabs_run_different_z_solve_kernels(pkg, O):
     orc = O.Oracle(po)
     try:
         orc.gpu_initialization()
-        start = O.perturb_fields(po, orc.fields())
+        f0 = orc.fields()
+        f0["c"] = np.full_like(f0["c"], po.chargeinf)  # (gpu_initialization leaves the ions to gpu_PBE: LBM.cu:111-146)
+        f0["cn"] = np.full_like(f0["cn"], po.chargeinf)
+        start = O.perturb_fields(po, f0)
         orc.set_fields(start)
         orc.fast_poisson()
         orc.init_equilibrium()
         orc.step(4)
         ref = orc.fields()
+        assert np.abs(ref["Ex"]).max() > 1.0  # a real field, not rounding noise
     finally:
         orc.close()
     p = _mirror(pkg, po)

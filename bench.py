@@ -588,6 +588,7 @@ def main():
                     help="N=1 only: run the multi-rank code path (split calls, comm stream, RCCL exchanges, the ring closing on the same rank)")
     ap.add_argument("--weak", action="store_true", help="the named grid is ONE RANK's slab; the channel is N of them (the 512^3-per-rank runs of rounds 1-2: --workload cfg3 --weak)")
     ap.add_argument("--scale-z", type=int, default=1, metavar="D", help="rehearsal: divide the z extent by D (several ranks sharing one GPU); the line says so")
+    ap.add_argument("--no-batch-ab", action="store_true", help="skip the after-the-fact A/B of the opt-in knob batch_moments (config.batch_moments_ab)")
     ap.add_argument("--no-comm-ab", action="store_true", help="skip the after-the-fact knob A/B of the library's transport (N>1 and --force-slab lines: `comm_ab`)")
     ap.add_argument("--comm-ab-steps", type=int, default=10, help="steps per leg of that A/B")
     ap.add_argument("--dry-run", action="store_true", help="check the launch plumbing only: rendezvous, barrier, one JSON line with the workload that WOULD run; no GPU")
@@ -844,6 +845,34 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # After the timed region, outside `value`: the opt-in knob "batch_moments" (include/ekpnp.h) - inside one step(n) call only the
+    # last step stores rho, u, c, cn, T.  The HEADLINE never uses it (every step of the timed region stores them, as the
+    # reference's step does, LBM.cu:807-813); this A/B says what a host that steps in batches between its outputs gets.
+    batch_ab = None
+    if not args.no_batch_ab and (native or not slab_path):
+        n_ab = max(10, min(args.steps, 40))
+
+        def timed_ms(n):
+            barrier()
+            t_ = time.perf_counter()
+            runner.step(n)
+            barrier()
+            v = (time.perf_counter() - t_) / n * 1e3
+            if dist is not None:
+                tv = torch.tensor([v], dtype=torch.float64)
+                dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+                v = float(tv.item())
+            return v
+
+        every = timed_ms(n_ab)
+        sol.tune("batch_moments", 1)
+        last_only = timed_ms(n_ab)
+        sol.tune("batch_moments", 0)
+        batch_ab = {"steps_per_call": n_ab, "every_step_stores_ms_per_step": round(every, 4), "last_step_stores_ms_per_step": round(last_only, 4),
+                    "every_step_stores_MLUPS": round(nx * ny * nz_global / every / 1e3, 1), "last_step_stores_MLUPS": round(nx * ny * nz_global / last_only / 1e3, 1),
+                    "note": "after the timed region, NOT the headline: ekpnp_tune(ctx, \"batch_moments\", 1) - inside one step(n) call only the last "
+                            "step stores the seven moment arrays (56 of the sweep's 1 808 B/node); same visible bits; HIP timing hooks off in both legs"}
+
     # After the timed region, outside `value`: a few steps under each knob that one GPU cannot decide, on the live
     # contexts (ekpnp_tune), so that ONE multi-GPU run says which default is right on xGMI.  Every rank runs every leg.
     comm_ab = None
@@ -929,6 +958,7 @@ def main():
                 # planes, the Poisson solve (on slabs: stage 1 to stage 3, exchanges included), and what is
                 # left of the step (wall planes, halo pack / unpack, dependency gaps)
                 "phases_ms_per_step": phases_of(dt, args.steps, k_ms, poisson_ms, n_solves),
+                "batch_moments_ab": batch_ab,
             },
             "roofline": {
                 "kernel": "k_collide_bulk",

@@ -110,6 +110,7 @@ int ctx_tune(Ctx& c, const char* knob, int value) {
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_wide") == 0 && (value == 0 || value == 1)) { c.tri_wide = value != 0 && c.tri_lds_ok && tridiag_wide_prepare_device(); drop_graph(c); return EKPNP_OK; }
+  if (std::strcmp(knob, "batch_moments") == 0 && (value == 0 || value == 1)) { c.batch_moments = value != 0; return EKPNP_OK; }
   if (std::strcmp(knob, "lazy_efield") == 0 && (value == 0 || value == 1)) {  // the A/B partner of the EPHI kernels: 0 = k_phi_efield in every solve
     const int rc = ensure_efield(c);
     c.lazy_efield = value;
@@ -142,6 +143,12 @@ namespace ekpnp {
 bool lazy_efield_ok(const Ctx& c) {
   return c.lazy_efield != 0 && c.p.n_lattices > 1 && !c.e_exposed && c.fld_owned[EKPNP_PHI] && c.fld_owned[EKPNP_EX] &&
          c.fld_owned[EKPNP_EY] && c.fld_owned[EKPNP_EZ];
+}
+bool batch_moments_ok(const Ctx& c) {
+  if (!c.batch_moments || c.mom_exposed || c.timing) return false;  // (measurement runs keep every step alike)
+  for (int id : {EKPNP_RHO, EKPNP_UX, EKPNP_UY, EKPNP_UZ, EKPNP_C, EKPNP_CN, EKPNP_T})
+    if (!c.fld_owned[id]) return false;  // a caller's own array (ekpnp_bind_field) may be read on the device at any time
+  return true;
 }
 int ensure_efield(Ctx& c) {
   if (!c.e_stale) return EKPNP_OK;
@@ -234,6 +241,7 @@ KArgs Ctx::kargs() const {
   a.rho0 = p.rho0; a.Ra = p.Ra; a.nu = p.nu; a.D = p.D;
   a.TH = p.TH;
   a.uw_multi = 2.0 * p.rho0 * p.uw / cs2 / p.CFL;  // LBM.cu:1896-1898 without the weight
+  a.wmom = skip_moments ? 0 : 1;
   a.rhs = p.n_lattices > 1 ? work : nullptr;
   a.eps = p.eps;
   a.rhs_wall_lo = p.voltage / p.dz / p.dz;    // poisson.cu:124
@@ -371,6 +379,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
   if (const char* e = std::getenv("EKPNP_LAZY_E")) c.lazy_efield = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("EKPNP_HALO_DIRECT")) c.halo_direct = std::atoi(e) != 0;
+  if (const char* e = std::getenv("EKPNP_BATCH_MOMENTS")) c.batch_moments = std::atoi(e) != 0;
   if (const char* e = std::getenv("EKPNP_MERGED_FACES")) c.merged_faces = std::atoi(e) != 0;
   if (const char* e = std::getenv("EKPNP_SLAB_LEAD_PLANES")) c.lead_planes = std::atoi(e) < 0 ? 0 : std::atoi(e);
   if (const char* e = std::getenv("EKPNP_EDGE_CHUNKS")) c.edge_chunks = std::atoi(e) < 1 ? 1 : (std::atoi(e) > 16 ? 16 : std::atoi(e));
@@ -603,6 +612,8 @@ extern "C" int ekpnp_field_device_ptr(ekpnp_ctx* ctx, int id, double** dptr) {
     // solve writes them (the eager path of rounds 1-3), and the collide reads the arrays
     if (int rc = ensure_efield(c)) return rc;
     if (!c.e_exposed) { c.e_exposed = true; drop_graph(c); }
+  } else {
+    c.mom_exposed = true;  // ... and every step stores the moments ("batch_moments" is off for this context from here on)
   }
   *dptr = c.fld[id];
   return EKPNP_OK;
@@ -1168,8 +1179,11 @@ extern "C" int ekpnp_step(ekpnp_ctx* ctx, int nsteps) {
       i += 2;
     }
   }
+  const bool batch = batch_moments_ok(c);
   for (; i < nsteps; ++i) {
+    c.skip_moments = batch && i < nsteps - 1;  // only the call's LAST step can be looked at
     int rc = one_step(ctx);
+    c.skip_moments = false;
     if (rc) return rc;
   }
   return EKPNP_OK;

@@ -104,6 +104,9 @@ struct KArgs {
   double* halo_out_up;
   const double* halo_in_lo;
   const double* halo_in_hi;
+  // 0: the bulk launch does not store rho, u, c, cn, T (an intermediate step of one ekpnp_step(n) call under the opt-in knob
+  // "batch_moments": nothing can look at them before the call's last step has written them); everything else is the same
+  int wmom;
 };
 
 // position of direction d among the 9 directions that cross a z face the way d does (up_dir / dn_dir): its slot in a halo buffer
@@ -234,6 +237,11 @@ struct Ctx {
   bool e_phi_valid = false;    // E == central differences of the phi array (true after every solve, false once E or phi were set from outside)
   bool e_exposed = false;      // ekpnp_field_device_ptr handed out phi / E: the caller may read or write them at any time -> eager from then on
   int lazy_efield = 1;         // knob (EKPNP_LAZY_E, ekpnp_tune "lazy_efield"): 0 = k_phi_efield in every solve, as in rounds 1-3
+  // opt-in knob (EKPNP_BATCH_MOMENTS, ekpnp_tune "batch_moments", default 0): inside ONE ekpnp_step(ctx, n) call only the LAST
+  // step's bulk launch stores the seven moment arrays (the steps before it cannot be looked at); 56 of the 1 808 B/node
+  bool batch_moments = false;
+  bool skip_moments = false;   // the step being enqueued is such an intermediate step (set and cleared by the step loops)
+  bool mom_exposed = false;    // ekpnp_field_device_ptr handed out one of rho, u, c, cn, T: every step stores them from then on
   bool streamed_state = true;  // true: pop[cur] holds X1 (post-stream, e.g. fresh equilibrium);
                                // false: pop[cur] holds post-collision populations (pull next)
   double* fld[EKPNP_NFIELDS] = {};
@@ -309,6 +317,8 @@ struct Ctx {
   PArgs pargs() const;
 };
 
+// capi.hip: may an intermediate step of a batch leave the moment arrays alone (knob on, all seven arrays the library's own, unexposed)?
+bool batch_moments_ok(const Ctx& c);
 // capi.hip: may this context leave E in phi (every one of phi, Ex, Ey, Ez is the library's own, unexposed array)?
 bool lazy_efield_ok(const Ctx& c);
 // capi.hip: bring the E arrays and phi's plates up to date if a lazy solve left them behind (no-op otherwise)

@@ -280,8 +280,9 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
       if (hb && act && zl == (ez_of(d) < 0 ? 0 : a.nzl - 1)) hb[((long long)lat * 9 + halo_slot(d)) * a.plane + (long long)y * a.nx + x] = v;
     }
   };
+  // (a.wmom == 0: an intermediate step of a batch, KArgs::wmom - uniform over the launch, a scalar branch)
   if (lat == 0) {
-    if (act) {  // LBM.cu:807-810
+    if (act && a.wmom) {  // LBM.cu:807-810
       a.fld[EKPNP_RHO][sidx] = rho;
       a.fld[EKPNP_UX][sidx] = ux;
       a.fld[EKPNP_UY][sidx] = uy;
@@ -290,7 +291,7 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
     collide_fluid(a, f, rho, ux, uy, uz, F, store);
   } else {
     const double m = lat == 1 ? c : lat == 2 ? cn : T;
-    if (act) a.fld[lat == 1 ? EKPNP_C : lat == 2 ? EKPNP_CN : EKPNP_T][sidx] = m;  // LBM.cu:811-813
+    if (act && a.wmom) a.fld[lat == 1 ? EKPNP_C : lat == 2 ? EKPNP_CN : EKPNP_T][sidx] = m;  // LBM.cu:811-813
     if (lat == 1 && act && a.rhs) {  // odd_extension's interior rows, poisson.cu:121-135, from registers
       a.rhs[sidx] = poisson_rhs_value(a.F, a.eps, c, cn, a.z0 + zl, a.nz, a.rhs_wall_lo, a.rhs_wall_hi);
     }

@@ -393,7 +393,10 @@ static int team_fast_poisson(Team& T) {
 static int team_step(Team& T, int nsteps) {  // main.cu:189-200
   if (nsteps < 0) { T.err = "nsteps < 0"; return EKPNP_ERR_INVALID; }
   for (int s = 0; s < nsteps; ++s) {
+    // opt-in "batch_moments": only the call's last step stores the moment arrays of the interior planes (capi.hip: ekpnp_step)
+    for (size_t i = 0; i < T.m.size(); ++i) S(T, (int)i).skip_moments = s < nsteps - 1 && batch_moments_ok(S(T, (int)i));
     int rc = team_stream_collide_save(T);
+    for (size_t i = 0; i < T.m.size(); ++i) S(T, (int)i).skip_moments = false;
     if (rc == EKPNP_OK) rc = team_fast_poisson(T);
     if (rc) return rc;
     for (size_t i = 0; i < T.m.size(); ++i) TSLAB(T, (int)i, ekpnp_advance_time(T.m[i]));

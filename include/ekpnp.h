@@ -273,6 +273,14 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
  * "tri_wide": 1 = 16 modes (wavefronts) per workgroup on columns of more than 256 rows (256-byte pieces of every row; 3 %
  * faster in isolation, default 0), same bits.
  * "lazy_efield": see ekpnp_fast_poisson; same bits.
+ * "batch_moments" (EKPNP_BATCH_MOMENTS, default 0 = the reference's behaviour, LBM.cu:807-813: every step stores rho, u, c,
+ * cn, T): 1 = inside ONE ekpnp_step(ctx, n) / ekpnp_group_step(g, n) call only the LAST step's sweep stores the seven moment
+ * arrays of the interior planes - nothing can look at the steps before it, and every array, diagnostic and file the caller
+ * can see after the call holds the same bits.  56 of the sweep's 1 808 B/node (3 %) for a host that steps in batches between
+ * its outputs, as main.cu's loop does between its NSAVE / printCurrent marks.  Off for a context whose moment arrays are
+ * caller-bound or exposed (ekpnp_bind_field, ekpnp_field_device_ptr) and while kernel timing is enabled; the split calls
+ * (ekpnp_stream_collide_save ...) always store.  bench.py's headline never uses it; the N=1 line reports it beside the
+ * headline as config.batch_moments_ab.
  * Slab contexts (same bits either way): "lead_planes" (EKPNP_SLAB_LEAD_PLANES, default 2): planes of the short launch
  * in front of the interior sweep that lets the exchange kernel in (0: none); "merged_faces" (EKPNP_MERGED_FACES, default 1):
  * both faces of a slab in one launch.

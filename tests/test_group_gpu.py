@@ -804,6 +804,37 @@ def test_transport_knobs_on_a_live_one_rank_ring(pkg, O):
         s.close()
 
 
+def test_batch_moments_on_slabs_changes_no_visible_bit(pkg, O):
+    """"batch_moments" through the transport: a 3-slab group (uneven: 8, 8, 9 planes) and a one-rank RCCL ring step in one call
+    of 6; the fields afterwards are the bits of the run that stores the moments in every step."""
+    po = O.default_params(48, 6, 25)
+    po.pb_iterations = 6
+    p = _mirror(pkg, po)
+    start = None
+    out = {}
+    for kind in ("group", "ring"):
+        for knob in (0, 1):
+            if kind == "group":
+                run = pkg.Group(p, 3, devices=[0, 0, 0])
+            else:
+                run = pkg.Solver(p, 0, 1, slab=True)
+                run.attach_comm(pkg.comm_unique_id())
+            try:
+                run.tune("batch_moments", knob)
+                run.initialization()
+                if start is None:
+                    start = O.perturb_fields(po, run.fields())
+                run.set_fields(start)
+                run.fast_Poisson()
+                run.init_equilibrium()
+                run.step(6)
+                out[kind, knob] = _fields_bits(run)
+            finally:
+                run.close()
+        for k in out[kind, 0]:
+            assert np.array_equal(out[kind, 0][k], out[kind, 1][k]), (kind, k)
+
+
 def test_group_tune_and_stage_times(pkg, O):
     po = O.default_params(70, 5, 32)
     po.pb_iterations = 5

@@ -183,6 +183,51 @@ def test_cfg1_at_its_own_size_on_the_hip_path(pkg, O):
         orc.close()
 
 
+@pytest.mark.parametrize("shape,in_place,nl", [((48, 10, 24), 0, 4), ((48, 10, 24), 1, 4), ((130, 6, 19), 0, 3), ((256, 256, 40), 0, 4)])
+def test_batch_moments_changes_no_visible_bit(pkg, O, shape, in_place, nl):
+    """The opt-in knob "batch_moments": inside one ekpnp_step(n) call only the last step stores rho, u, c, cn, T (LBM.cu:807-813
+    stores them every step).  Everything a caller can see after the call - all eleven fields, the diagnostics, and the run's
+    continuation - must hold the same bits as without the knob: small lattices (k_collide_all, hipGraph replay), in place,
+    three lattices, and a lattice large enough for the separate bulk kernel (256 x 256 x 40)."""
+    po = O.default_params(*shape)
+    po.pb_iterations = 6
+    po.n_lattices = nl
+    if nl < 4:
+        po.Ra = 0.0
+    p = _mirror(pkg, po)
+    p.in_place = in_place
+    res = []
+    start = None
+    for knob in (0, 1):
+        with pkg.Solver(p) as s:
+            s.tune("batch_moments", knob)
+            s.initialization()
+            if start is None:
+                start = O.perturb_fields(po, s.fields())
+            s.set_fields(start)
+            s.fast_Poisson()
+            s.init_equilibrium()
+            s.step(7)
+            a = {k: v.copy() for k, v in s.fields().items()}
+            cur, um = s.current(), s.umax()
+            s.step(1)  # a batch of one: stores
+            s.step(4)
+            b = {k: v.copy() for k, v in s.fields().items()}
+            res.append((a, b, cur, um))
+    (a0, b0, c0, u0), (a1, b1, c1, u1) = res
+    for k in a0:
+        assert np.array_equal(a0[k], a1[k]) and np.array_equal(b0[k], b1[k]), k
+    assert c0 == c1 and u0 == u1
+    if nl == 4 and shape[0] < 256:  # and the knobbed run against the oracle
+        orc = O.Oracle(po)
+        try:
+            orc.set_fields(start); orc.fast_poisson(); orc.init_equilibrium(); orc.step(12)
+            e = O.rel_l2(b1, orc.fields())
+        finally:
+            orc.close()
+        assert all(v <= (TOL_U if k == "u" else TOL) for k, v in e.items()), e
+
+
 def test_moving_wall_and_body_force(pkg, O):
     po = O.default_params(20, 6, 11)
     po.pb_iterations = 10

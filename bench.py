@@ -208,6 +208,78 @@ def min_max_by_rank(dicts: list) -> dict:
     return {"min": {k: round(min(d[k] for d in dicts), 4) for k in keys}, "max": {k: round(max(d[k] for d in dicts), 4) for k in keys}}
 
 
+class HeadlineGuard:
+    """Keeps the measured line safe from what runs AFTER the timed region (the knob A/Bs, the copy probe, the CPU baseline).
+
+    Those legs are outside `value`, but they run before the ONE JSON line is printed, and on the first real multi-GPU run
+    they are the least rehearsed code: an RCCL exchange under an untried knob that never completes, or an exception on one
+    rank while its peers sit in a collective, would take the headline with it.  So every rank arms a timer when its timed
+    region has closed; rank 0 hands it the line as it stands (update() after every finished leg).  If the legs are not done
+    `deadline_s` later, rank 0 writes that line - marked `after_the_fact.status = "abandoned"`, naming the leg - straight to the
+    saved stdout descriptor, and every rank ends itself with os._exit(0): the measurement is complete and valid, the process
+    is not allowed to hang on its appendix.  (os._exit, not an exec and not a signal to anybody else: the driver's launcher
+    sees N ranks that ended with 0.)  finish() prints the complete line instead and disarms; whichever comes first wins."""
+
+    def __init__(self, rank: int, deadline_s: float, fd: int = 1, exit_fn=None):
+        import threading
+
+        self.rank, self.deadline_s, self.fd = rank, float(deadline_s), fd
+        self._lock = threading.Lock()
+        self._line = None       # rank 0: the line as JSON text, as of the last finished leg
+        self._leg = "start"
+        self._done = False
+        self._timer = None
+        self._exit = exit_fn if exit_fn is not None else os._exit
+        self._threading = threading
+
+    def arm(self, out=None):
+        with self._lock:
+            if out is not None:
+                self._line = dict(out)
+            if self.deadline_s > 0 and self._timer is None:
+                self._timer = self._threading.Timer(self.deadline_s, self._fire)
+                self._timer.daemon = True
+                self._timer.start()
+
+    def update(self, out=None, leg=None):
+        with self._lock:
+            if out is not None:
+                self._line = dict(out)
+            if leg is not None:
+                self._leg = leg
+
+    def _write(self, obj):
+        data = (json.dumps(obj) + "\n").encode()
+        while data:
+            data = data[os.write(self.fd, data):]
+
+    def _fire(self):
+        with self._lock:
+            if self._done:
+                return
+            self._done = True
+            if self._line is not None:
+                line = dict(self._line)
+                line["after_the_fact"] = {"status": "abandoned", "leg": self._leg, "deadline_s": self.deadline_s,
+                                          "note": "the timed region had closed and `value` stands; a leg that runs after it did not finish in time"}
+                self._write(line)
+            print(f"bench.py: rank {self.rank}: the after-the-fact leg '{self._leg}' did not finish within {self.deadline_s:.0f} s; "
+                  "the headline was measured before it and is printed; leaving", file=sys.stderr, flush=True)
+            self._exit(0)
+
+    def finish(self, out=None):
+        """the normal end: print the complete line (rank 0) and disarm.  False if the timer won the race (the line is out already)."""
+        with self._lock:
+            if self._done:
+                return False
+            self._done = True
+            if self._timer is not None:
+                self._timer.cancel()
+            if out is not None:
+                self._write(out)
+            return True
+
+
 def comm_ab_leg(label, knobs, sol, runner, steps, barrier, dist, torch, world, base=None):
     """ONE leg of the after-the-fact knob A/B: `steps` steps of the live context under `knobs` (set through ekpnp_tune on every
     rank, in the same order), timed like the headline (barrier + sync both sides, max over ranks), with what the compute
@@ -457,7 +529,7 @@ def cpu_baseline_in_child(nl: int):
     import subprocess
 
     env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(nl)], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(nl)], env=env, capture_output=True, text=True, timeout=240)
     if r.returncode != 0:
         raise RuntimeError("CPU-baseline child failed: " + r.stderr[-2000:])
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -591,6 +663,9 @@ def main():
     ap.add_argument("--no-batch-ab", action="store_true", help="skip the after-the-fact A/B of the opt-in knob batch_moments (config.batch_moments_ab)")
     ap.add_argument("--no-comm-ab", action="store_true", help="skip the after-the-fact knob A/B of the library's transport (N>1 and --force-slab lines: `comm_ab`)")
     ap.add_argument("--comm-ab-steps", type=int, default=10, help="steps per leg of that A/B")
+    ap.add_argument("--after-deadline", type=float, default=300.0, metavar="SECONDS",
+                    help="what runs after the timed region (knob A/Bs, copy probe, CPU baseline) gets this long; then the measured line is printed "
+                         "as it stands, marked, and every rank leaves (class HeadlineGuard).  0: no deadline")
     ap.add_argument("--dry-run", action="store_true", help="check the launch plumbing only: rendezvous, barrier, one JSON line with the workload that WOULD run; no GPU")
     ap.add_argument("--cpu-baseline-only", type=int, default=None, metavar="LATTICES", help="internal: time the CPU oracle and print its JSON (the child of cpu_baseline_in_child)")
     args = ap.parse_args()
@@ -845,60 +920,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # After the timed region, outside `value`: the opt-in knob "batch_moments" (include/ekpnp.h) - inside one step(n) call only the
-    # last step stores rho, u, c, cn, T.  The HEADLINE never uses it (every step of the timed region stores them, as the
-    # reference's step does, LBM.cu:807-813); this A/B says what a host that steps in batches between its outputs gets.
-    batch_ab = None
-    if not args.no_batch_ab and (native or not slab_path):
-        n_ab = max(10, min(args.steps, 40))
-
-        def timed_ms(n):
-            barrier()
-            t_ = time.perf_counter()
-            runner.step(n)
-            barrier()
-            v = (time.perf_counter() - t_) / n * 1e3
-            if dist is not None:
-                tv = torch.tensor([v], dtype=torch.float64)
-                dist.all_reduce(tv, op=dist.ReduceOp.MAX)
-                v = float(tv.item())
-            return v
-
-        every = timed_ms(n_ab)
-        sol.tune("batch_moments", 1)
-        last_only = timed_ms(n_ab)
-        sol.tune("batch_moments", 0)
-        batch_ab = {"steps_per_call": n_ab, "every_step_stores_ms_per_step": round(every, 4), "last_step_stores_ms_per_step": round(last_only, 4),
-                    "every_step_stores_MLUPS": round(nx * ny * nz_global / every / 1e3, 1), "last_step_stores_MLUPS": round(nx * ny * nz_global / last_only / 1e3, 1),
-                    "note": "after the timed region, NOT the headline: ekpnp_tune(ctx, \"batch_moments\", 1) - inside one step(n) call only the last "
-                            "step stores the seven moment arrays (56 of the sweep's 1 808 B/node); same visible bits; HIP timing hooks off in both legs"}
-
-    # After the timed region, outside `value`: a few steps under each knob that one GPU cannot decide, on the live
-    # contexts (ekpnp_tune), so that ONE multi-GPU run says which default is right on xGMI.  Every rank runs every leg.
-    comm_ab = None
-    if native and not args.no_comm_ab and args.comm_ab_steps > 0:
-        base = ab_baseline()
-        comm_ab = []
-        for label, knobs in COMM_AB_LEGS:
-            comm_ab.append(comm_ab_leg(label, knobs, sol, runner, args.comm_ab_steps, barrier, dist, torch, world, base))
-
     rho = sol.get_field("rho")
     finite = bool(np.isfinite(rho).all())
+    del rho
     nodes_total = nx * ny * nz_global
     mlups = nodes_total * args.steps / dt / 1e6
 
+    # ---- the line as the timed region left it (rank 0), BEFORE anything else runs: HeadlineGuard keeps it safe -------------
+    out = None
     if rank == 0:
         launches_per_step = max(1, n_launch // max(1, args.steps))
         k_avg_ms = k_ms / max(1, n_launch)
         bytes_per_launch = b_alg_lbm(nl) * k_nodes
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-        # secondary denominator: what a plain contiguous copy reaches on THIS device, now
-        copy_gbs = None
-        try:
-            free_now, _ = torch.cuda.mem_get_info()
-            copy_gbs = sol.copy_bandwidth(min(2 << 30, free_now // 4))
-        except Exception as exc:  # e.g. no room for the scratch buffers next to a 276 GB lattice
-            print(f"copy-bandwidth probe skipped: {exc}", file=sys.stderr)
         # HBM traffic of one launch from the PMC counters: NOT measured by this run (counters need
         # rocprofv3 around the process) - the value of the committed profile of this workload, with
         # where it comes from; null if the profile does not cover this workload
@@ -958,7 +992,7 @@ def main():
                 # planes, the Poisson solve (on slabs: stage 1 to stage 3, exchanges included), and what is
                 # left of the step (wall planes, halo pack / unpack, dependency gaps)
                 "phases_ms_per_step": phases_of(dt, args.steps, k_ms, poisson_ms, n_solves),
-                "batch_moments_ab": batch_ab,
+                "batch_moments_ab": None,
             },
             "roofline": {
                 "kernel": "k_collide_bulk",
@@ -969,8 +1003,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "copy_GBps": round(copy_gbs, 1) if copy_gbs else None,
-                "frac_of_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                "copy_GBps": None,
+                "frac_of_copy": None,
                 "bytes_per_node": b_alg_lbm(nl),
                 "nodes_per_launch": int(k_nodes),
                 "launches_per_step": launches_per_step,
@@ -987,17 +1021,101 @@ def main():
             if all(st is not None for st in all_stages):
                 # where a solve's time goes on a slab: stage 1 | EDGE all-gather as the compute stream saw it | stage 2 | PHI exchange | stage 3
                 out["config"]["poisson_stages_ms_per_solve_by_rank"] = min_max_by_rank(all_stages)
-            if comm_ab is not None:
+
+    # Everything below runs after the timed region and outside `value`.  It must not be able to lose the line above: every
+    # rank arms the guard now (class HeadlineGuard), each leg is tried on its own, and the line goes out whatever they do.
+    if saved_stdout is not None:
+        sys.stdout.flush()
+    guard = HeadlineGuard(rank, args.after_deadline, fd=saved_stdout if saved_stdout is not None else 1)
+    guard.arm(out)
+    after_errors = {}
+
+    def leg(name, fn):
+        """one after-the-fact leg: named to the guard, never fatal to the line (an exception is recorded under its name)"""
+        guard.update(leg=name)
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001
+            after_errors[name] = f"{type(e).__name__}: {e}"
+            print(f"bench.py: rank {rank}: after-the-fact leg '{name}' failed: {after_errors[name]}", file=sys.stderr)
+            return None
+
+    if rank == 0:
+        # secondary denominator (SURVEY.md 8(d)): what a plain contiguous copy reaches on THIS device, now
+        def copy_probe():
+            free_now, _ = torch.cuda.mem_get_info()
+            return sol.copy_bandwidth(min(2 << 30, free_now // 4))  # (may not fit next to a 276 GB lattice: then the leg reports that)
+
+        copy_gbs = leg("copy_bandwidth", copy_probe)
+        if copy_gbs:
+            out["roofline"]["copy_GBps"] = round(copy_gbs, 1)
+            out["roofline"]["frac_of_copy"] = round(out["roofline"]["achieved"] / copy_gbs, 4)
+        guard.update(out)
+
+    # The opt-in knob "batch_moments" (include/ekpnp.h) - inside one step(n) call only the last step stores rho, u, c, cn, T.
+    # The HEADLINE never uses it (every step of the timed region stores them, as the reference's step does, LBM.cu:807-813);
+    # this A/B says what a host that steps in batches between its outputs gets.
+    if not args.no_batch_ab and (native or not slab_path):
+        n_ab = max(10, min(args.steps, 40))
+
+        def timed_ms(n):
+            barrier()
+            t_ = time.perf_counter()
+            runner.step(n)
+            barrier()
+            v = (time.perf_counter() - t_) / n * 1e3
+            if dist is not None:
+                tv = torch.tensor([v], dtype=torch.float64)
+                dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+                v = float(tv.item())
+            return v
+
+        def batch_leg():
+            every = timed_ms(n_ab)
+            sol.tune("batch_moments", 1)
+            try:
+                last_only = timed_ms(n_ab)
+            finally:
+                sol.tune("batch_moments", 0)
+            return {"steps_per_call": n_ab, "every_step_stores_ms_per_step": round(every, 4), "last_step_stores_ms_per_step": round(last_only, 4),
+                    "every_step_stores_MLUPS": round(nx * ny * nz_global / every / 1e3, 1), "last_step_stores_MLUPS": round(nx * ny * nz_global / last_only / 1e3, 1),
+                    "note": "after the timed region, NOT the headline: ekpnp_tune(ctx, \"batch_moments\", 1) - inside one step(n) call only the last "
+                            "step stores the seven moment arrays (56 of the sweep's 1 808 B/node); same visible bits; HIP timing hooks off in both legs"}
+
+        batch_ab = leg("batch_moments_ab", batch_leg)
+        if out is not None:
+            out["config"]["batch_moments_ab"] = batch_ab
+            guard.update(out)
+
+    # A few steps under each knob that one GPU cannot decide, on the live contexts (ekpnp_tune), so that ONE multi-GPU run
+    # says which default is right on xGMI.  Every rank runs every leg.
+    if native and not args.no_comm_ab and args.comm_ab_steps > 0:
+        base = ab_baseline()
+        comm_ab = []
+        for label, knobs in COMM_AB_LEGS:
+            r = leg(f"comm_ab: {label}", lambda: comm_ab_leg(label, knobs, sol, runner, args.comm_ab_steps, barrier, dist, torch, world, base))  # noqa: B023
+            comm_ab.append(r if r is not None else {"knob": label, "error": after_errors.get(f"comm_ab: {label}", "failed")})
+            if out is not None:
                 out["comm_ab"] = {"note": f"after the timed region, outside `value`: {args.comm_ab_steps} steps per leg on the live contexts "
                                           "(ekpnp_tune on every rank); ms_per_step and the waits are maxima over the ranks; the timed region ran with `baseline`",
-                                  "baseline": ab_baseline(), "legs": comm_ab}
+                                  "baseline": ab_baseline(), "legs": list(comm_ab)}
+                guard.update(out)
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            runner.close()
-            out["cpu_baseline"] = cpu_baseline_in_child(nl)
-        if saved_stdout is not None:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
+            def cpu_leg():
+                runner.close()
+                return cpu_baseline_in_child(nl)
+
+            cb = leg("cpu_baseline", cpu_leg)
+            out["cpu_baseline"] = cb if cb is not None else {"error": after_errors.get("cpu_baseline"), "kind": "port", "value": None, "unit": "MLUPS", "cores": None,
+                                                             "sample": "not measured: the CPU-baseline child failed (message in `error`)"}
+        if after_errors:
+            out["after_the_fact"] = {"status": "legs failed", "errors": after_errors}
+        sys.stdout.flush()
+    guard.finish(out)  # rank 0: the ONE JSON line, on the real stdout; every rank: disarm
+    if saved_stdout is not None:
+        os.dup2(saved_stdout, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

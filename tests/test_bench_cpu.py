@@ -1,7 +1,11 @@
 """bench.py's bookkeeping without a GPU: the algorithmic bytes of SURVEY.md §8(d) and the choice
 of the workload from the free device memory."""
 import importlib.util
+import json
 import os
+import subprocess
+import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -327,3 +331,52 @@ def test_comm_ab_legs_agree_over_two_gloo_ranks(tmp_path):
         for _, k, v in tunes:
             final[k] = v
         assert final == {"inline_exchanges": 1, "comm_cus": 0, "lead_planes": 2, "edge_chunks": 1}
+
+
+def test_headline_guard_prints_the_measured_line_when_a_later_leg_hangs(tmp_path):
+    """What runs after the timed region (knob A/Bs, copy probe, CPU baseline) must not be able to lose the measured line:
+    a leg that never returns ends in the line as it stood, marked, and exit code 0 - in a real process, through os._exit."""
+    script = tmp_path / "hang.py"
+    script.write_text(
+        "import sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "g = bench.HeadlineGuard(0, 0.5)\n"
+        "g.arm({'metric': 'MLUPS (full EK-PNP step)', 'value': 3268.0, 'config': {'batch_moments_ab': None}})\n"
+        "g.update({'metric': 'MLUPS (full EK-PNP step)', 'value': 3268.0, 'config': {'batch_moments_ab': {'x': 1}}}, leg='comm_ab: comm_cus=8')\n"
+        "time.sleep(60)\n"
+        "print('never')\n")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "never" not in r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] == 3268.0 and d["config"]["batch_moments_ab"] == {"x": 1}  # the line as of the last finished leg
+    assert d["after_the_fact"]["status"] == "abandoned" and d["after_the_fact"]["leg"] == "comm_ab: comm_cus=8"
+    assert "comm_ab: comm_cus=8" in r.stderr
+
+
+def test_headline_guard_other_ranks_leave_quietly_and_finish_wins_the_race():
+    b = _bench()
+    rd, wr = os.pipe()
+    left = []
+    # a rank without the line (rank > 0): nothing on stdout, it just leaves with 0
+    g = b.HeadlineGuard(3, 0.05, fd=wr, exit_fn=left.append)
+    g.arm(None)
+    time.sleep(0.5)
+    assert left == [0]
+    assert g.finish({"late": True}) is False  # the timer won: nothing more is written
+    # the normal end: the complete line, once, and a timer that never fires afterwards
+    g2 = b.HeadlineGuard(0, 0.3, fd=wr, exit_fn=left.append)
+    g2.arm({"value": 1.0})
+    assert g2.finish({"value": 1.0, "cpu_baseline": {"value": 4.2}}) is True
+    time.sleep(0.6)
+    assert left == [0]
+    os.close(wr)
+    got = os.read(rd, 1 << 16).decode().splitlines()
+    os.close(rd)
+    assert [json.loads(x) for x in got] == [{"value": 1.0, "cpu_baseline": {"value": 4.2}}]
+    # deadline 0: never armed
+    g3 = b.HeadlineGuard(0, 0.0, exit_fn=left.append)
+    g3.arm({"value": 2.0})
+    assert g3._timer is None

@@ -691,6 +691,19 @@ def main():
 
     import torch
 
+    # stdout is for the ONE JSON line.  C-level writers share fd 1 with it - gloo announces its connections there
+    # ("[Gloo] Rank 0 is connected to 1 peer ranks ...", from EVERY rank, when the process group is made), RCCL prints a
+    # version banner when its first communicator is made - so fd 1 points at stderr from here on, in every rank, and the
+    # line goes out through the saved descriptor (HeadlineGuard / emit below).
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        data = (json.dumps(obj) + "\n").encode()
+        while data:
+            data = data[os.write(saved_stdout, data):]
+
     # control plane (rendezvous, barrier, max over ranks): torch.distributed over gloo, CPU tensors.
     # The DATA path of --backend nccl is RCCL inside libekpnp.so, not torch.
     dist = None
@@ -716,13 +729,13 @@ def main():
             ipc_env = [None] * world
             dist.all_gather_object(ipc_env, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
         if rank == 0:
-            print(json.dumps({"metric": "MLUPS (full EK-PNP step)", "value": None, "unit": "MLUPS", "n_gpus": world, "dry_run": True, "scaling": sel["scaling"],
+            emit({"metric": "MLUPS (full EK-PNP step)", "value": None, "unit": "MLUPS", "n_gpus": world, "dry_run": True, "scaling": sel["scaling"],
                               "env_by_rank": {"HSA_ENABLE_IPC_MODE_LEGACY": ipc_env},  # what the ranks of THIS launch mode run with
                               "transport": ("none (one context)" if world == 1 and not args.force_slab else
                                             "RCCL inside libekpnp.so" if native_dry else
                                             "torch.distributed example transport (rehearsal / FALLBACK)"),
                               "config": {"workload": sel["label"], "grid": list(sel["grid"]), "lattices": sel["lattices"], "nodes_per_rank": sel["nodes_per_rank"],
-                                         "planes_per_rank": sel["planes_per_rank"], "scaling_note": sel["scaling_note"]}}), flush=True)
+                                         "planes_per_rank": sel["planes_per_rank"], "scaling_note": sel["scaling_note"]}})
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -763,13 +776,6 @@ def main():
     native = transport_or_exit(pkg, torch, dist, rank, slab_path and args.backend == "nccl", args.allow_fallback_transport)
     if slab_path and args.backend == "nccl" and not native:
         fell_back = True
-    saved_stdout = None
-    if slab_path:
-        # RCCL prints a version banner on the C-level stdout when its first communicator is made;
-        # stdout is for the ONE JSON line, so fd 1 points at stderr until that line is printed
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
     p = pkg.default_params(nx, ny, nz_global)
     p.n_lattices = nl
     if nl < 4:
@@ -1024,9 +1030,8 @@ def main():
 
     # Everything below runs after the timed region and outside `value`.  It must not be able to lose the line above: every
     # rank arms the guard now (class HeadlineGuard), each leg is tried on its own, and the line goes out whatever they do.
-    if saved_stdout is not None:
-        sys.stdout.flush()
-    guard = HeadlineGuard(rank, args.after_deadline, fd=saved_stdout if saved_stdout is not None else 1)
+    sys.stdout.flush()
+    guard = HeadlineGuard(rank, args.after_deadline, fd=saved_stdout)
     guard.arm(out)
     after_errors = {}
 
@@ -1114,8 +1119,8 @@ def main():
             out["after_the_fact"] = {"status": "legs failed", "errors": after_errors}
         sys.stdout.flush()
     guard.finish(out)  # rank 0: the ONE JSON line, on the real stdout; every rank: disarm
-    if saved_stdout is not None:
-        os.dup2(saved_stdout, 1)
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -204,6 +204,9 @@ def test_ranks_launched_by_torch_distributed_run_get_the_ipc_mode_too():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
     assert out["env_by_rank"]["HSA_ENABLE_IPC_MODE_LEGACY"] == ["0", "0"]
+    # stdout of this launch mode is the ONE line and nothing else: gloo's "[Gloo] Rank r is connected to ..." lines (C-level
+    # writes to fd 1 from every rank, found by the GPU test of this launch) go to stderr like RCCL's banner
+    assert [l for l in r.stdout.splitlines() if l.strip()] == [json.dumps(out)], r.stdout[-2000:]
     # an explicit setting of the caller is respected, not overwritten
     r = subprocess.run(cmd, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -1,6 +1,7 @@
 """GPU tests of the z-slab path: P slabs must reproduce the single-context
 result - the LBM part bit for bit (same kernels, same arithmetic per node), the Poisson part to
 rounding (the distributed tridiagonal associates differently)."""
+import json
 import os
 import socket
 import subprocess
@@ -262,3 +263,36 @@ def test_native_rccl_two_ranks_full_width_planes(pkg, O, tmp_path, own_fft):
         assert int(d["ranks_on_device"]) == 2 and bool(d["own_passes"]) == (own_fft is None)
     if own_fft is None:
         _assert_vs_oracle(O, got, _oracle_from(O, po, st, 6), parts)  # 6.3 M nodes x 6 steps on the host cores
+
+
+def test_bench_under_the_drivers_launcher_two_rccl_ranks(tmp_path):
+    """bench.py ITSELF, started the way the driver starts an N>1 run (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W`), with two real RCCL
+    ranks of the library's transport on the box's one device (--single-device: the functional rehearsal, not a bandwidth
+    figure).  The first run on a multi-GPU node cannot be repeated cheaply, so the whole line is checked here: exit 0, ONE
+    JSON line on stdout and nothing else, the driver's keys, `comm`, per-rank phases and solve stages, every `comm_ab` leg
+    without an error, `batch_moments_ab`, no `after_the_fact` mark (class HeadlineGuard stayed quiet), finite fields."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)  # bench.py must set it for the ranks of this launch mode by itself
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--single-device", "--workload", "128x128x48", "--comm-ab-steps", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, r.stdout[-2000:]  # RCCL's banner and everything else went to stderr
+    d = json.loads(out[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["dtype"] == "f64" and d["value"] > 0
+    assert d["transport_fallback"] is False and d["config"]["transport"].startswith("RCCL inside libekpnp.so")
+    assert d["config"]["planes_per_rank"] == [24, 24] and d["config"]["finite"] is True
+    assert "after_the_fact" not in d
+    assert d["comm"]["halo"]["exchanges_per_step"] == 1 and len(d["comm"]["wait_ms_per_step_by_rank"]) == 2
+    assert set(d["config"]["phases_ms_per_step_by_rank"]) == {"min", "max"}
+    assert set(d["config"]["poisson_stages_ms_per_solve_by_rank"]["max"]) == {"stage1", "edge_exchange", "stage2", "phi_exchange", "stage3"}
+    legs = d["comm_ab"]["legs"]
+    assert [g["knob"] for g in legs][0] == "defaults" and len(legs) >= 5
+    assert not [g for g in legs if "error" in g], legs
+    assert d["config"]["batch_moments_ab"]["last_step_stores_ms_per_step"] > 0
+    assert d["config"]["plane_transforms"]["ranks_on_device"] == 2

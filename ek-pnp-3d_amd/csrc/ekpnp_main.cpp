@@ -59,6 +59,7 @@ int main(int argc, char* argv[]) {
   std::string out = ".";
   double exf = 0.0, uw = 0.0, chargeinf = -1.0, Ra = -1.0, TH = -1.0;
   double converged_tol = 0.0;  // > 0: ekpnp_initialization_converged instead of the reference's fixed 501 Picard sweeps
+  int batch = 0;  // 1: ekpnp_step(n) from one output mark to the next instead of one stream_collide_save + fast_Poisson pair per iteration
   std::vector<std::pair<std::string, int>> tunes;  // --tune knob=value: ekpnp_tune / ekpnp_group_tune right after creation
   for (int i = 1; i < argc; ++i) {
     auto val = [&](const char* name) -> const char* {
@@ -92,6 +93,7 @@ int main(int argc, char* argv[]) {
     else if ((v = val("--Ra"))) Ra = std::atof(v);
     else if ((v = val("--TH"))) TH = std::atof(v);
     else if ((v = val("--converged-init"))) converged_tol = std::atof(v);
+    else if ((v = val("--batch"))) batch = std::atoi(v);
     else if ((v = val("--tune"))) {
       const char* eq = std::strchr(v, '=');
       if (!eq || eq == v) { std::fprintf(stderr, "--tune wants knob=value, got %s\n", v); return 2; }
@@ -102,7 +104,10 @@ int main(int argc, char* argv[]) {
                    "usage: ekpnp_main [--nx N --ny N --nz N] [--steps N] [--nsave N] [--print-current N] [--read-previous 0|1|2]\n"
                    "                  [--binary-state 0|1] [--gpus N [--transport auto|rccl|copy] [--devices d0,d1,...]]\n"
                    "                  [--lattices 1|3|4] [--exf F --uw U --chargeinf C --Ra R --TH T] [--out DIR] [--converged-init TOL]\n"
-                   "                  [--tune knob=value ...]\n"
+                   "                  [--tune knob=value ...] [--batch 0|1]\n"
+                   "  --batch 1: the time loop advances with ONE ekpnp_step(ctx, n) call from each output mark (Tecplot zone, current / umax\n"
+                   "  line) to the next, with the knob batch_moments on (only the last step of a call stores rho, u, c, cn, T: nothing looks at\n"
+                   "  the steps in between); the same files, byte for byte, as the default loop, which mirrors main.cu:189-224 call by call.\n"
                    "  --tune knob=value: a launch-shape or transport knob of include/ekpnp.h's ekpnp_tune (with --gpus N: on every slab), e.g.\n"
                    "  edge_chunks=4 (the slab Poisson solve's all-gather in 4 pipelined blocks), lead_planes=0, inline_exchanges=0, comm_cus=8;\n"
                    "  the results are the same bits under every setting.\n"
@@ -149,6 +154,7 @@ int main(int argc, char* argv[]) {
     int rc = ekpnp_create(&P, &ctx);
     if (rc != EKPNP_OK) return fail("ekpnp_create", rc);
   }
+  if (batch) tunes.insert(tunes.begin(), std::make_pair(std::string("batch_moments"), 1));  // (an explicit --tune batch_moments=0 comes later and wins)
   for (const auto& kv : tunes) {
     const int rc = grp ? ekpnp_group_tune(grp, kv.first.c_str(), kv.second) : ekpnp_tune(ctx, kv.first.c_str(), kv.second);
     if (rc != EKPNP_OK) return fail(("--tune " + kv.first).c_str(), rc);
@@ -187,9 +193,18 @@ int main(int argc, char* argv[]) {
   CK(RUN(synchronize));
   const auto begin = std::chrono::steady_clock::now();  // main.cu:185-186
   for (unsigned i = 0; i < nsteps; i++) {               // main.cu:189-224
-    CK(RUN(stream_collide_save, t));
-    CK(RUN(fast_poisson));
-    t = t + P.dt;
+    if (batch) {
+      // iterations i .. j in one call, j = the next iteration something looks at the fields (or the last one)
+      unsigned j = i;
+      while (j + 1 < nsteps && !(j % nsave == 1 || j % print_current == 1)) ++j;
+      CK(RUN(step, (int)(j - i + 1)));
+      for (unsigned k = i; k <= j; ++k) t = t + P.dt;  // the same additions as the loop below makes, so the files carry the same time
+      i = j;
+    } else {
+      CK(RUN(stream_collide_save, t));
+      CK(RUN(fast_poisson));
+      t = t + P.dt;
+    }
     if (i % nsave == 1) {
       CK(RUN(save_data_tecplot, f_data.c_str(), 1, t, 1));
       std::printf("Iteration: %u, physical time: %g.\n", i, t);

@@ -242,6 +242,33 @@ def test_cpp_driver_with_slabs_writes_the_single_gpu_files(pkg, tmp_path):
     assert r.returncode == 0 and "Reading previous data..." in r.stdout, r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("extra", [[], ["--devices", "0,0,0"]])
+def test_ekpnp_main_batch_loop_writes_the_same_files(tmp_path, extra):
+    """ekpnp_main --batch 1: ONE ekpnp_step(n) / ekpnp_group_step(n) call from each output mark to the next, with the knob
+    batch_moments on (only a call's last step stores rho, u, c, cn, T) - the way a host gets the 56 B/node back that bench.py
+    reports beside its headline.  Every file of the run (data.dat with its three zones, umax.dat, data_end.dat, the lossless
+    data_end.bin) and every `Current =` line equals the default loop's, which mirrors main.cu:189-224 call by call - byte for
+    byte, on one context and on three slabs."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ek-pnp-3d_amd", "ekpnp_main")
+    if not os.path.exists(exe):
+        pytest.skip("ekpnp_main not built")
+    geo = ["--nx", "40", "--ny", "6", "--nz", "33", "--steps", "47", "--nsave", "15", "--print-current", "10", "--uw", "3e-4", "--binary-state", "1"]
+    runs = {}
+    for tag, opt in (("loop", []), ("batch", ["--batch", "1"])):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([exe, *geo, *extra, *opt, "--out", str(d)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        runs[tag] = (d, [l for l in r.stdout.splitlines() if l.startswith("Iteration:")])
+    (da, la), (db, lb) = runs["loop"], runs["batch"]
+    assert la == lb and len([l for l in la if "Current = " in l]) == 5
+    for f in ("data.dat", "umax.dat", "data_end.dat", "data_end.bin"):
+        a, b = (da / f).read_bytes(), (db / f).read_bytes()
+        assert len(a) > 0 and a == b, f
+
+
 # ---- BASELINE cfg4 / cfg5 at their full per-rank shapes (size-independent properties) -------------
 
 def _uniform_profiles(run, p, steps):

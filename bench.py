@@ -756,6 +756,17 @@ def main():
         os.environ.setdefault("EKPNP_PLACEMENT_TRIES", "1")
         # (round 4 also forced rocFFT's plans here; round 5 found the cause - hardware-queue oversubscription, GPU_MAX_HW_QUEUES
         # above - and the own plane transforms run at full speed on a shared device too)
+    ndev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    nodev = local_rank >= ndev
+    if dist is not None:  # the ranks leave together, before anybody waits for a rank that is gone
+        flag = torch.tensor([1 if nodev else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        nodev = bool(int(flag.item()))
+    if nodev:
+        if dist is not None:
+            dist.destroy_process_group()
+        raise SystemExit(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) {'has no device of its own' if local_rank >= ndev else 'leaves with the others'}: {ndev} HIP device(s) visible for {world} ranks - "
+                         "one rank per GPU, or --single-device for a functional rehearsal of the N>1 path on one GPU (labelled, not a scaling figure)")
     torch.cuda.set_device(local_rank)
     pkg = G.load_package()
 

@@ -383,3 +383,23 @@ def test_headline_guard_other_ranks_leave_quietly_and_finish_wins_the_race():
     g3 = b.HeadlineGuard(0, 0.0, exit_fn=left.append)
     g3.arm({"value": 2.0})
     assert g3._timer is None
+
+
+def test_more_ranks_than_devices_ends_every_rank_with_a_message():
+    """`bench.py --gpus 2` under the driver's launcher on a box with fewer HIP devices than ranks (here: none): every rank
+    leaves together, non-zero, with one sentence that names --single-device - no traceback from torch.cuda.set_device, no rank
+    left waiting in a collective, nothing on stdout."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # (a GPU box that runs this file too: no device for anybody)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    msgs = [l for l in r.stderr.splitlines() if l.startswith("bench.py: rank")]
+    assert len(msgs) == 2 and all("--single-device" in m and "0 HIP device(s) visible for 2 ranks" in m for m in msgs), r.stderr[-3000:]
+    assert r.stdout.strip() == ""

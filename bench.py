@@ -750,6 +750,11 @@ def main():
         os.environ["NCCL_HOSTID"] = f"ekpnp-rehearsal-rank{rank}"
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    if world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world:
+        # every rank is on this node (the contract: N GPUs of ONE node): RCCL's bootstrap needs no network interface but the
+        # loopback, whatever else the container shows it; the data path between the GPUs (P2P over xGMI) is not chosen by this.
+        # Set before librccl loads; an explicit setting wins.  (Reported in the line: config.rccl_env.)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     if args.single_device and world > 1:
         # ranks sharing one device must not race for its free memory: the placement search of ekpnp_create holds up to two
         # extra population arenas for a moment, and a rank that loses that race would leave its peers in ncclCommInitRank
@@ -1004,6 +1009,8 @@ def main():
                 "placement": sol.placement_report(),
                 # the library's own row / column passes or rocFFT plans; ranks of this lattice on rank 0's device (> 1: a rehearsal)
                 "plane_transforms": sol.plane_transforms(),
+                # what RCCL was told through the environment (N>1; rehearsals add NCCL_HOSTID: ranks on one device pose as hosts)
+                "rccl_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES")} if slab_path else None,
                 "finite": finite,
                 # HIP events on the context's stream inside the timed region: the collide sweep of the interior
                 # planes, the Poisson solve (on slabs: stage 1 to stage 3, exchanges included), and what is

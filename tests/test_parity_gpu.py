@@ -842,6 +842,29 @@ def test_drawn_configurations_vs_oracle(pkg, O, seed):
         assert abs(cur - want_cur) <= 1e-6 * abs(want_cur) + 1e-24, tag
 
 
+def test_random_call_sequences_vs_oracle(pkg, O):
+    """The library's bookkeeping BETWEEN calls (lazy E validity, the fused right-hand side, graph capture, batch flags, buffer
+    parity): 16 seeded random sequences of the C ABI's calls - step(n), the split pair, fast_Poisson alone, get_field, set_field
+    of E / phi / c / cn / moments mid-run, init_equilibrium mid-run, ekpnp_tune, ekpnp_field_device_ptr, ekpnp_bind_field with
+    device writes, ekpnp_invalidate_rhs, checkpoints into a new context of the other population mode or a group of slabs -
+    mirrored call by call on the oracle (tools/api_fuzz.py ran 600 of them once: profiles/r05b_api_fuzz_600.json)."""
+    import importlib.util
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("api_fuzz", os.path.join(root, "tools", "api_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    me = sys.modules[__name__]
+    n_ops = 0
+    for seed in range(2000, 2016):
+        ok, ops, worst, err = fz.one_sequence(pkg, O, me, seed, None)
+        n_ops += len(ops) - 1
+        _REPORT.append({"test": "random_call_sequences", "mark": f"seed {seed}: " + " | ".join(ops), "rel_l2": worst})
+        assert ok, (seed, ops, err)
+    assert n_ops > 100
+
+
 def test_anisotropic_spacings_vs_oracle(pkg, O):
     """dx != dy != dz and a box that is not NX dx long: the Poisson solve takes kx, ky from Lx, Ly
     (main.cu:119-136), its z operator from dz (poisson.cu:176) and E from dx, dy, dz

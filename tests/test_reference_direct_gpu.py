@@ -318,6 +318,83 @@ def test_reference_kernels_live_at_cfg2_scale(pkg, O, tmp_path):
             os.remove(tmp_path / f"L_step{step}.bin")
 
 
+@pytest.mark.parametrize("seed", [31, 32, 33, 34, 35, 36])
+def test_reference_kernels_live_drawn_physics(pkg, O, tmp_path, seed):
+    """The reference's own kernels RUN HERE on physics nobody chose by hand: every symbol ref_driver can set at run time
+    (hipMemcpyToSymbol, no source edit: voltage, voltage2, Ext, TH, Ra, K, Kn, diffu, diffun, nu, D, exf, uw, VC, VCn, V, VT,
+    chargeinf, eps) drawn within 30 % of the G8 set, the plates' potentials exchanged now and then, moving wall / body force
+    on or off - on the reference's default 50x8x51 grid (oracle/_ref/ref_driver), from a perturbed 3-D start, six steps with a
+    dump after every one.  The HIP path gets the same fields and parameters through the C ABI and is compared with the
+    reference's output DIRECTLY after every step (the reference's DC constant of each solve read off its own phi and injected
+    as in the live test above).  Skipped when the binary is not there (build() makes it where /root/reference is)."""
+    import importlib.util
+    import subprocess
+
+    import bench
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = os.path.join(root, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(drv):
+        pytest.skip("oracle/_ref/ref_driver not built (oracle/build_ref.sh)")
+    spec = importlib.util.spec_from_file_location("make_golden", golden_path("make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = 50, 8, 51
+    n = nx * ny * nz
+    p = pkg.default_params(nx, ny, nz)
+    p.Lx, p.Ly, p.Lz = 0.5e-6, 0.08e-6, 0.5e-6  # literals of LBM.h:40-42
+    p.pb_iterations = 60
+    phys = {k: float(v) * float(rng.uniform(0.7, 1.3)) for k, v in mg.ASYM.items()}
+    if rng.random() < 0.5:
+        phys["voltage"], phys["voltage2"] = phys["voltage2"], phys["voltage"]
+    if rng.random() < 0.35:
+        phys["uw"] = 0.0
+    if rng.random() < 0.35:
+        phys["exf"] = 0.0
+    for k, v in phys.items():
+        setattr(p, k, v)
+    name = f"reference_live_drawn_physics[{seed}]"
+    marks = [1, 2, 3, 4, 5, 6]
+
+    def read_bin(path):
+        a = np.fromfile(path, dtype=np.float64)
+        assert a.size == 11 * n, (path, a.size)
+        return {k: a[i * n:(i + 1) * n].reshape(nz, ny, nx) for i, k in enumerate(O.FIELDS)}
+
+    with pkg.Solver(p) as s:
+        s.initialization()
+        bench.apply_perturbation(s, None, p)
+        start = s.fields()
+        inp = tmp_path / "in.bin"
+        with open(inp, "wb") as f:
+            for k in O.FIELDS:
+                f.write(np.ascontiguousarray(start[k]).tobytes())
+        sets = []
+        for k, v in phys.items():
+            sets += ["--set", f"{k}={v!r}"]
+        r = subprocess.run([drv, str(tmp_path), *sets, "fields", str(inp), "D", *[str(m) for m in marks]], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+
+        def leak_of(ref_phi, hip_phi):
+            d = ref_phi[1:-1] - hip_phi[1:-1]
+            sh = float(d.mean())
+            assert np.abs(d - sh).max() <= 1e-15, ("the reference's phi minus the exact solve is not one constant", np.abs(d - sh).max())
+            return sh
+
+        s.fast_Poisson()
+        ref = read_bin(tmp_path / "D_step0.bin")
+        inject_leak(s, p, leak_of(ref["phi"], s.get_field("phi")))
+        _check(O, name, 0, {k: s.get_field(k) for k in ("phi", "Ex", "Ey", "Ez")}, ref, {"phi": ["phi"], "E": ["Ex", "Ey", "Ez"]})
+        s.init_equilibrium()
+        for step in marks:
+            s.stream_collide_save()
+            s.fast_Poisson()
+            ref = read_bin(tmp_path / f"D_step{step}.bin")
+            inject_leak(s, p, leak_of(ref["phi"], s.get_field("phi")))
+            _check(O, name, step, s.fields(), ref, wall_fraction=1.0)
+
+
 # ---- G4: the reference's POPULATIONS, kernel by kernel, against the HIP path's own state ------------------
 # D3Q27 directions in the reference's numbering (SURVEY.md 8(a) a1; LBM.cu:1983-2008): c[d] = (cx, cy, cz)
 _C27 = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (1, 1, 0), (-1, -1, 0), (1, 0, 1), (-1, 0, -1),

@@ -259,8 +259,11 @@ def test_asymmetric_physics_G8_hip_vs_reference_direct(pkg, O, grid):
             _check(O, name, f"perturbed {mark}", sub(s.fields()), {k: g[f"a2_step{mark}_{k}"] for k in O.FIELDS})
 
 
-def test_reference_kernels_live_at_cfg2_scale(pkg, O, tmp_path):
-    """The reference's own kernels RUN HERE, on a 15.7 M-node lattice (250x250x251 - cfg2's scale; NX must be
+@pytest.mark.parametrize("nslabs", [1, 3])
+def test_reference_kernels_live_at_cfg2_scale(pkg, O, tmp_path, nslabs):
+    """(nslabs = 3, round 5: the same lattice as THREE uneven z slabs of the multi-GPU path - ekpnp_group_* on device 0, halo ring,
+    distributed z solve - against the reference's single-device kernels.)
+    The reference's own kernels RUN HERE, on a 15.7 M-node lattice (250x250x251 - cfg2's scale; NX must be
     a multiple of the reference's 10-thread blocks), against the HIP path on the same input: one Poisson
     solve and two full steps, all 11 fields.  Uses oracle/_ref/ref_driver_250x250x251 (the reference's
     LBM.cu / poisson.cu built for gfx950 by `oracle/build_ref.sh 250x250x251`; it travels to the GPU box
@@ -278,14 +281,15 @@ def test_reference_kernels_live_at_cfg2_scale(pkg, O, tmp_path):
     nx, ny, nz = 250, 250, 251
     n = nx * ny * nz
     p = pkg.default_params(nx, ny, nz)
-    name = "reference_live_250x250x251"
+    name = "reference_live_250x250x251" + ("" if nslabs == 1 else f"_{nslabs}_slabs")
 
     def read_bin(path):
         a = np.fromfile(path, dtype=np.float64)
         assert a.size == 11 * n, (path, a.size)
         return {k: a[i * n:(i + 1) * n].reshape(nz, ny, nx) for i, k in enumerate(O.FIELDS)}
 
-    with pkg.Solver(p) as s:
+    with (pkg.Solver(p) if nslabs == 1 else pkg.Group(p, nslabs, devices=[0] * nslabs)) as s:
+        s.z0 = 0  # (bench's start-state helpers address a rank's planes: a whole lattice starts at plane 0)
         prof, _ = bench.pb_profile_from_product(pkg, p)
         bench.product_pb_state(s, p, prof)
         bench.apply_perturbation(s, None, p)

@@ -107,6 +107,7 @@ int ctx_tune(Ctx& c, const char* knob, int value) {
   // mode blocks of the slab z solve: the layout of the edge buffers changes with it, so only a context whose exchanges the
   // library moves itself may ask for more than one (an external transport gathers the whole buffer in one piece)
   if (std::strcmp(knob, "edge_chunks") == 0 && value >= 1 && value <= 16 && c.slab && (value == 1 || c.team)) { c.edge_chunks = value; return EKPNP_OK; }
+  if (std::strcmp(knob, "poisson_blocks") == 0 && value >= 0 && value <= 256 && !c.slab) { c.poisson_blocks = value; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_wide") == 0 && (value == 0 || value == 1)) { c.tri_wide = value != 0 && c.tri_lds_ok && tridiag_wide_prepare_device(); drop_graph(c); return EKPNP_OK; }
@@ -382,6 +383,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   if (const char* e = std::getenv("EKPNP_BATCH_MOMENTS")) c.batch_moments = std::atoi(e) != 0;
   if (const char* e = std::getenv("EKPNP_MERGED_FACES")) c.merged_faces = std::atoi(e) != 0;
   if (const char* e = std::getenv("EKPNP_SLAB_LEAD_PLANES")) c.lead_planes = std::atoi(e) < 0 ? 0 : std::atoi(e);
+  if (const char* e = std::getenv("EKPNP_POISSON_BLOCKS")) c.poisson_blocks = std::atoi(e) < 0 ? 0 : (std::atoi(e) > 256 ? 256 : std::atoi(e));
   if (const char* e = std::getenv("EKPNP_EDGE_CHUNKS")) c.edge_chunks = std::atoi(e) < 1 ? 1 : (std::atoi(e) > 16 ? 16 : std::atoi(e));
   {
     const char* e = std::getenv("EKPNP_TRI_WIDE");
@@ -738,9 +740,21 @@ static int poisson_single(Ctx& c, bool allow_lazy) {
   if (trc) return trc;
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
-  if (int frc = plane_fft_forward(c)) return frc;
-  launch_tridiag(c);
-  if (int frc = plane_fft_inverse(c)) return frc;
+  if (const int nb = poisson_block_count(c); nb > 1) {
+    // column blocks: the three middle passes of one kx block back to back (poisson.hip: poisson_block)
+    if (int frc = plane_fft_forward_rows(c)) return frc;
+    for (int k = 0; k < nb; ++k) {
+      const ModeBlock blk = poisson_block(c, k);
+      plane_fft_forward_columns(c, blk);
+      launch_tridiag(c, &blk);
+      plane_fft_inverse_columns(c, blk);
+    }
+    if (int frc = plane_fft_inverse_rows(c)) return frc;
+  } else {
+    if (int frc = plane_fft_forward(c)) return frc;
+    launch_tridiag(c);
+    if (int frc = plane_fft_inverse(c)) return frc;
+  }
   const bool lazy = allow_lazy && lazy_efield_ok(c);
   if (!lazy) launch_phi_efield(c);
   mark_solved(c, lazy);

@@ -175,7 +175,9 @@ void launch_poisson_rhs(Ctx&);
 int plane_fft_setup(Ctx&);      // decides Ctx::own_fft for this lattice and device, makes the twiddle table
 int plane_fft_forward(Ctx&);    // fft_in() -> fft_spec(): the own kernels or the rocFFT plan; EKPNP_OK or a status with Ctx::err set
 int plane_fft_inverse(Ctx&);    // fft_spec() -> fft_out()
-void launch_tridiag(Ctx&);
+void launch_tridiag(Ctx&, const ModeBlock* block = nullptr);  // the whole spectrum, or the kx columns of one block
+int poisson_block_count(const Ctx&);                    // column blocks of a single context's solve (Ctx::poisson_blocks; 1 where they do not apply)
+ModeBlock poisson_block(const Ctx&, int block);
 bool tridiag_prepare_device();  // per-device function attributes of the partition z solves (current device)
 bool tridiag_wide_prepare_device();  // ... of the 16-wavefront forms (128 KB of LDS)
 void launch_phi_efield(Ctx&);
@@ -271,6 +273,8 @@ struct Ctx {
   double* edge_all = nullptr;      // [nranks][4][modes]
   int edge_chunks = 1;             // mode blocks of the slab z solve (ekpnp_tune "edge_chunks" on a context with a transport, EKPNP_EDGE_CHUNKS):
                                    // > 1: the EDGE all-gather of block k runs on the comm stream beside the column pass of block k + 1
+  int poisson_blocks = 0;          // single context (0: decided from the spectrum's size, poisson.hip: poisson_block_count): kx column blocks of the solve's middle passes (y forward, z solve, y inverse of one block back to
+                                   // back, so that the block stays in the Infinity Cache between them; ekpnp_tune "poisson_blocks", EKPNP_POISSON_BLOCKS)
   double* phi_old = nullptr;       // PB relaxation state (ekpnp_pbe_begin/end)
   double* diag = nullptr;          // reduction scratch (DIAG_SCRATCH doubles)
   double* vwall = nullptr;         // {voltage, voltage, voltage2, voltage2}

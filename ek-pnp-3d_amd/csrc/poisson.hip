@@ -345,7 +345,7 @@ __device__ __forceinline__ void tridiag_part_solve(const PArgs& a, double2* __re
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l = lane % LANES;                 // lane within its mode: owns slots R l .. R l + R - 1
   const int col = w * MPW + lane / LANES;     // the mode among the workgroup's MC
-  const double b = mode_diag((int)(SLAB ? block_mode(a, m0 + col) : m0 + col), a.ny, a.nxh, a.Lx, a.Ly, a.dz);
+  const double b = mode_diag((int)block_mode(a, m0 + col), a.ny, a.nxh, a.Lx, a.Ly, a.dz);  // (the whole spectrum is the block 0, nxh)
   const double dz2 = a.dz * a.dz;
   double2* mine = img + (R * l) * MC + (col ^ (l & FM));
   double2 g[R];
@@ -439,8 +439,8 @@ __device__ __forceinline__ void tridiag_part_body(const PArgs& a, double2* __res
   using TP = TriPart<R, LANES, NW>;
   extern __shared__ double2 tp_lds[];    // [LANES R slots][MC columns] = R x NW KB
   const long long ms = (long long)a.ny * a.nxh;
-  const long long m0 = (long long)blockIdx.x * TP::MC;  // SLAB: numbered within the kernel's mode block (block_mode)
-  const long long mcol = SLAB ? block_mode(a, m0 + threadIdx.x % TP::MC) : m0 + threadIdx.x % TP::MC;
+  const long long m0 = (long long)blockIdx.x * TP::MC;  // numbered within the kernel's mode block (block_mode)
+  const long long mcol = block_mode(a, m0 + threadIdx.x % TP::MC);
   {
     double2 v[R];
     TP::load(rows, ms, mcol, n, v);
@@ -1205,12 +1205,48 @@ bool tridiag_wide_prepare_device() {
 // launch + name of one instantiation of the partition solve
 #define TRI_PART(RR, LL, GROUP, NAME)                                                                                            \
     do {                                                                                                                         \
-        hipLaunchKernelGGL((k_tridiag_part<RR, LL>), dim3(nm / (GROUP)), dim3(512), (RR) * 8192, c.stream, a);                   \
+        hipLaunchKernelGGL((k_tridiag_part<RR, LL>), dim3(nb / (GROUP)), dim3(512), (RR) * 8192, c.stream, a);                   \
         note_launch(c, "k_tridiag_part<" NAME ">");                                                                              \
     } while (0)
-void launch_tridiag(Ctx& c) {
+// ---- column blocks of the single context's solve ("poisson_blocks", ekpnp_internal.h: Ctx::poisson_blocks) ----------------
+// The three middle passes of a solve - y forward, z solve, y inverse - all work on kx COLUMNS of the half spectrum (every ky,
+// every plane of a kx range).  Taken block by block, the three passes of one block back to back, a block that fits the
+// 256 MiB Infinity Cache is read from HBM once and written once instead of three times each.  Same kernels, same
+// instantiation (chosen on the whole spectrum, as for the slab's mode blocks), every mode solved by itself: same bits.
+// Only where the library's own column passes and a partition solve run (cfg2 ... cfg5 plane shapes); else one block.
+static bool tridiag_is_partition(const Ctx& c) {
+  const int nm = c.p.ny * c.nxh, rows = c.p.nz - 2;
+  const bool part = c.tri_partition > 0 && c.tri_lds_ok && c.nxh % 8 == 0;
+  const bool large = c.tri_partition > 1 || (size_t)nm * (size_t)rows >= (size_t)4 * 1024 * 1024;
+  return part && large && rows > 64 && rows <= 512;
+}
+// Measured (profiles/r05c_ab_poisson_blocks*.jsonl, MI355X): half spectra of 1.1 GB - cfg3's 512 x 512 x 512 and a 1024 x 1024 x
+// 128 context - gain 0.13 ms per solve with THREE blocks (2.11 -> 1.97 ms inside cfg3's step; 2, 4, 6 blocks gain less, 11 and
+// more lose: narrow blocks are read in short pieces, tools/mall_probe.hip prices that footprint at +0.2 ms per pass, more
+// than the cache gives back), spectra of 0.13 - 0.27 GB (256^3, 512 x 512 x 128) gain nothing or lose 0.02 - 0.1 ms.  Hence the
+// default (Ctx::poisson_blocks == 0): three blocks from 768 MiB of half spectrum on, one below.
+int poisson_block_count(const Ctx& c) {
+  if (c.slab || !c.own_fft || c.poisson_blocks == 1 || !tridiag_is_partition(c)) return 1;
+  int want = c.poisson_blocks;
+  if (want <= 0) want = (size_t)c.p.ny * c.nxh * (size_t)(c.p.nz - 2) * sizeof(double2) >= ((size_t)768 << 20) ? 3 : 1;
+  const int gu = block_unit_groups(c), units = (c.nxh / 8 + gu - 1) / gu;
+  return want > units ? units : want;
+}
+ModeBlock poisson_block(const Ctx& c, int k) {
+  ModeBlock b{};
+  const int groups = c.nxh / 8, gu = block_unit_groups(c), units = (groups + gu - 1) / gu, nb = poisson_block_count(c);
+  const int u0 = (int)((long long)units * k / nb), u1 = (int)((long long)units * (k + 1) / nb);
+  const int g0 = u0 * gu, g1 = u1 * gu < groups ? u1 * gu : groups;
+  b.x0 = nb == 1 ? 0 : g0 * 8;
+  b.bw = nb == 1 ? c.nxh : (g1 - g0) * 8;
+  return b;
+}
+
+void launch_tridiag(Ctx& c, const ModeBlock* blk) {
   PArgs a = c.pargs();
-  const int nm = c.p.ny * c.nxh;
+  if (blk) { a.bx0 = blk->x0; a.bw = blk->bw; }
+  const int nm = c.p.ny * c.nxh;   // the kernel is chosen on the WHOLE spectrum
+  const int nb = c.p.ny * a.bw;    // modes of this launch
   // c.tri_partition (ekpnp_tune "tri_partition" / EKPNP_TRI_PARTITION): 0 the serial sweeps everywhere (the A/B
   // partner of k_tridiag_part), 1 the partition solve on large lattices, 2 wherever it applies (tests)
   const bool part = c.tri_partition > 0 && c.tri_lds_ok && c.nxh % 8 == 0;
@@ -1228,7 +1264,7 @@ void launch_tridiag(Ctx& c) {
     TRI_PART(4, 64, 8, "4");
   } else if (part && large && rows <= 512 && c.tri_wide && nm % 16 == 0) {
     // 16 wavefronts = 16 adjacent modes per workgroup: every row is read and written in 256-byte pieces instead of 128-byte ones
-    hipLaunchKernelGGL((k_tridiag_part<8, 64, 16>), dim3(nm / 16), dim3(1024), 16 * 8192, c.stream, a);
+    hipLaunchKernelGGL((k_tridiag_part<8, 64, 16>), dim3(nb / 16), dim3(1024), 16 * 8192, c.stream, a);
     note_launch(c, "k_tridiag_part<8,64,16>");
   } else if (part && large && rows <= 512) {
     TRI_PART(8, 64, 8, "8");

@@ -272,6 +272,11 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
  * 2 = wherever it applies; the two solve the same system in a different elimination order (equal to rounding).
  * "tri_wide": 1 = 16 modes (wavefronts) per workgroup on columns of more than 256 rows (256-byte pieces of every row; 3 %
  * faster in isolation, default 0), same bits.
+ * "poisson_blocks" (EKPNP_POISSON_BLOCKS; single contexts on 512- / 1024-wide planes whose z solve is the partition solve):
+ * the solve's three middle passes - y forward, z solve, y inverse - taken kx block by kx block, the three passes of one block
+ * back to back, so that part of a block is still in the 256 MiB Infinity Cache when the next pass wants it.  0 (default) = the
+ * library decides from the half spectrum's size (three blocks from 768 MiB on - cfg3: 2.11 -> 1.97 ms per solve -, one below),
+ * 1 = one block (the A/B partner), n = n blocks.  Same kernels, every mode solved by itself: same bits for every count.
  * "lazy_efield": see ekpnp_fast_poisson; same bits.
  * "batch_moments" (EKPNP_BATCH_MOMENTS, default 0 = the reference's behaviour, LBM.cu:807-813: every step stores rho, u, c,
  * cn, T): 1 = inside ONE ekpnp_step(ctx, n) / ekpnp_group_step(g, n) call only the LAST step's sweep stores the seven moment

@@ -985,6 +985,56 @@ def test_sixteen_modes_per_workgroup_is_bitwise_the_default_z_solve(pkg, O):
         assert np.isfinite(res[0]).all() and np.array_equal(res[0], res[1])
 
 
+def test_column_blocks_of_the_solve_are_bitwise_the_one_block_solve(pkg):
+    """ekpnp_tune "poisson_blocks" (round 5): y forward, z solve and y inverse of one kx block back to back (the block is partly
+    still in the Infinity Cache between them; three blocks are the default from 768 MiB of half spectrum on = cfg3).  Same
+    kernels, the z-solve instantiation chosen on the whole spectrum, every mode solved by itself: phi must not change by a
+    bit for any block count - 512-wide planes (the own column passes), 70 and 200 planes (k_tridiag_part<8,32>, <4>), random
+    charges; block counts that divide the 33 column groups and ones that do not, and more blocks than groups."""
+    for nz in (70, 200):
+        shape = (512, 512, nz)
+        p = pkg.default_params(*shape)
+        p.n_lattices = 1
+        p.chargeinf = 0.0
+        p.Ra = 0.0
+        rng = np.random.default_rng(31 + nz)
+        cc, cn = 0.01 * (1 + 0.5 * rng.random(shape[::-1])), 0.01 * (1 + 0.5 * rng.random(shape[::-1]))
+        with pkg.Solver(p) as s:
+            s.tune("tri_partition", 2)
+            s.set_field("c", cc); s.set_field("cn", cn)
+            ref = None
+            for nb in (1, 0, 2, 3, 5, 11, 33, 200):
+                s.tune("poisson_blocks", nb)
+                s.fast_Poisson()
+                phi = s.get_field("phi")
+                if ref is None:
+                    ref = phi
+                    assert np.isfinite(ref).all() and np.abs(ref).max() > 1e-4
+                assert np.array_equal(ref, phi), f"poisson_blocks = {nb} changed phi on {shape}"
+        del cc, cn
+    # the time loop (the collide's fused right-hand side, lazy E, hipGraph replay) through three blocks and through one
+    shape = (512, 512, 70)
+    p = pkg.default_params(*shape)
+    p.n_lattices = 3
+    p.Ra = 0.0
+    p.pb_iterations = 2
+    rng = np.random.default_rng(37)
+    cc, cn = 0.01 * (1 + 0.05 * rng.random(shape[::-1])), 0.01 * (1 + 0.05 * rng.random(shape[::-1]))
+    res = []
+    for nb in (1, 3):
+        with pkg.Solver(p) as s:
+            s.tune("tri_partition", 2)
+            s.tune("poisson_blocks", nb)
+            s.initialization()
+            s.set_field("c", cc); s.set_field("cn", cn)
+            s.fast_Poisson()
+            s.init_equilibrium()
+            s.step(4)
+            res.append({k: s.get_field(k) for k in ("phi", "c", "cn", "ux", "uz", "Ez")})
+    for k, v in res[0].items():
+        assert np.isfinite(v).all() and np.array_equal(v, res[1][k]), k
+
+
 @pytest.mark.parametrize("dz", [1.0e-11, 1.0e-5])
 def test_partition_z_solve_extreme_anisotropy_vs_oracle(pkg, O, dz):
     """The same extremes against the ORACLE (its 3-D DFT of the odd extension, the reference's algorithm, poisson.cu:75-204),

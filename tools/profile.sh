@@ -11,7 +11,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --workload $WL --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --workload $WL --no-cpu-baseline --no-batch-ab --no-comm-ab"  # (the after-the-fact A/B legs would dilute the per-kernel means)
 echo "== kernel trace" && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 10 --warmup 2 > "$OUT/trace.log" 2>&1 || exit 1
 echo "== pmc FETCH_SIZE" && timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $BENCH --steps 3 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1 || exit 1
 echo "== pmc WRITE_SIZE" && timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o pmc -- $BENCH --steps 3 --warmup 1 > "$OUT/pmc_write.log" 2>&1 || exit 1

@@ -101,6 +101,7 @@ static void drop_graph(Ctx& c);
 namespace ekpnp {
 int ctx_tune(Ctx& c, const char* knob, int value) {
   if (std::strcmp(knob, "ab_zchunk") == 0 && value >= 0) { c.ab_zchunk = value; return EKPNP_OK; }
+  if (std::strcmp(knob, "bulk_yband") == 0 && value >= -1 && value < 0x7fff) { c.bulk_yband = value; drop_graph(c); return EKPNP_OK; }
   // slab launch shapes (same bits either way): the lead-in launch of the interior sweep, one launch for both faces
   if (std::strcmp(knob, "lead_planes") == 0 && value >= 0 && c.slab) { c.lead_planes = value; return EKPNP_OK; }
   if (std::strcmp(knob, "merged_faces") == 0 && (value == 0 || value == 1) && c.slab) { c.merged_faces = value != 0; return EKPNP_OK; }
@@ -108,6 +109,7 @@ int ctx_tune(Ctx& c, const char* knob, int value) {
   // library moves itself may ask for more than one (an external transport gathers the whole buffer in one piece)
   if (std::strcmp(knob, "edge_chunks") == 0 && value >= 1 && value <= 16 && c.slab && (value == 1 || c.team)) { c.edge_chunks = value; return EKPNP_OK; }
   if (std::strcmp(knob, "poisson_blocks") == 0 && value >= 0 && value <= 256 && !c.slab) { c.poisson_blocks = value; drop_graph(c); return EKPNP_OK; }
+  if (std::strcmp(knob, "poisson_zchunk") == 0 && value >= 0 && !c.slab) { c.poisson_zchunk = value; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "merged_walls") == 0) { c.merged_walls = value != 0; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_partition") == 0 && value >= 0 && value <= 2) { c.tri_partition = value; drop_graph(c); return EKPNP_OK; }
   if (std::strcmp(knob, "tri_wide") == 0 && (value == 0 || value == 1)) { c.tri_wide = value != 0 && c.tri_lds_ok && tridiag_wide_prepare_device(); drop_graph(c); return EKPNP_OK; }
@@ -377,6 +379,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   c.tri_lds_ok = tridiag_prepare_device();
   if (hipDeviceGetAttribute(&c.ncus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || c.ncus < 1) { (void)hipGetLastError(); c.ncus = 256; }
   if (const char* e = std::getenv("EKPNP_BULK_ZCHUNK")) c.ab_zchunk = std::atoi(e) > 0 ? std::atoi(e) : 0;
+  if (const char* e = std::getenv("EKPNP_BULK_YBAND")) c.bulk_yband = std::atoi(e) < -1 ? -1 : (std::atoi(e) > 0x7ffe ? 0x7ffe : std::atoi(e));
   c.merged_walls = std::getenv("EKPNP_NO_MERGED_WALLS") == nullptr;
   if (const char* e = std::getenv("EKPNP_LAZY_E")) c.lazy_efield = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("EKPNP_HALO_DIRECT")) c.halo_direct = std::atoi(e) != 0;
@@ -384,6 +387,7 @@ static int create_impl(const ekpnp_params* p, int rank, int nranks, bool slab, e
   if (const char* e = std::getenv("EKPNP_MERGED_FACES")) c.merged_faces = std::atoi(e) != 0;
   if (const char* e = std::getenv("EKPNP_SLAB_LEAD_PLANES")) c.lead_planes = std::atoi(e) < 0 ? 0 : std::atoi(e);
   if (const char* e = std::getenv("EKPNP_POISSON_BLOCKS")) c.poisson_blocks = std::atoi(e) < 0 ? 0 : (std::atoi(e) > 256 ? 256 : std::atoi(e));
+  if (const char* e = std::getenv("EKPNP_POISSON_ZCHUNK")) c.poisson_zchunk = std::atoi(e) < 0 ? 0 : std::atoi(e);
   if (const char* e = std::getenv("EKPNP_EDGE_CHUNKS")) c.edge_chunks = std::atoi(e) < 1 ? 1 : (std::atoi(e) > 16 ? 16 : std::atoi(e));
   {
     const char* e = std::getenv("EKPNP_TRI_WIDE");
@@ -740,16 +744,33 @@ static int poisson_single(Ctx& c, bool allow_lazy) {
   if (trc) return trc;
   if (!c.rhs_ready) launch_poisson_rhs(c);
   c.rhs_ready = false;
-  if (const int nb = poisson_block_count(c); nb > 1) {
-    // column blocks: the three middle passes of one kx block back to back (poisson.hip: poisson_block)
-    if (int frc = plane_fft_forward_rows(c)) return frc;
+  const int nb = poisson_block_count(c);
+  const int zc = c.own_fft && c.poisson_zchunk > 0 && c.poisson_zchunk < c.fft_nz ? c.poisson_zchunk : 0;
+  if (nb > 1 || zc) {
+    // The passes in pieces that stay in the Infinity Cache from one pass to the next (poisson.hip: poisson_block; same kernels,
+    // same bits).  Plane chunks: rows + columns of one run of planes back to back; column blocks: the middle passes of one
+    // kx block back to back.  Both: forward by plane chunks, then z solve + y inverse by column blocks, then all rows.
+    const ModeBlock all = poisson_block_whole(c);
+    if (zc) {
+      for (int z0 = 0; z0 < c.fft_nz; z0 += zc) {
+        const int n = c.fft_nz - z0 < zc ? c.fft_nz - z0 : zc;
+        if (int frc = plane_fft_forward_rows(c, z0, n)) return frc;
+        plane_fft_forward_columns(c, all, z0, n);
+      }
+    } else if (int frc = plane_fft_forward_rows(c)) return frc;
     for (int k = 0; k < nb; ++k) {
-      const ModeBlock blk = poisson_block(c, k);
-      plane_fft_forward_columns(c, blk);
-      launch_tridiag(c, &blk);
-      plane_fft_inverse_columns(c, blk);
+      const ModeBlock blk = nb > 1 ? poisson_block(c, k) : all;
+      if (!zc) plane_fft_forward_columns(c, blk);
+      launch_tridiag(c, nb > 1 ? &blk : nullptr);
+      if (nb > 1) plane_fft_inverse_columns(c, blk);
     }
-    if (int frc = plane_fft_inverse_rows(c)) return frc;
+    if (nb == 1) {  // (plane chunks only)
+      for (int z0 = 0; z0 < c.fft_nz; z0 += zc) {
+        const int n = c.fft_nz - z0 < zc ? c.fft_nz - z0 : zc;
+        plane_fft_inverse_columns(c, all, z0, n);
+        if (int frc = plane_fft_inverse_rows(c, z0, n)) return frc;
+      }
+    } else if (int frc = plane_fft_inverse_rows(c)) return frc;
   } else {
     if (int frc = plane_fft_forward(c)) return frc;
     launch_tridiag(c);

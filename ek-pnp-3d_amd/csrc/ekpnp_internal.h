@@ -178,6 +178,7 @@ int plane_fft_inverse(Ctx&);    // fft_spec() -> fft_out()
 void launch_tridiag(Ctx&, const ModeBlock* block = nullptr);  // the whole spectrum, or the kx columns of one block
 int poisson_block_count(const Ctx&);                    // column blocks of a single context's solve (Ctx::poisson_blocks; 1 where they do not apply)
 ModeBlock poisson_block(const Ctx&, int block);
+ModeBlock poisson_block_whole(const Ctx&);              // all kx columns
 bool tridiag_prepare_device();  // per-device function attributes of the partition z solves (current device)
 bool tridiag_wide_prepare_device();  // ... of the 16-wavefront forms (128 KB of LDS)
 void launch_phi_efield(Ctx&);
@@ -185,10 +186,10 @@ void launch_slab_thomas_local(Ctx&, int block = 0);    // stage 1 of the slab z 
 void launch_slab_reduce_correct(Ctx&, int block = 0);  // stage 2 on mode block `block` (its edge values gathered)
 int edge_chunk_count(const Ctx&);                       // mode blocks of this context's slab solve (Ctx::edge_chunks, at most nxh / 8)
 ModeBlock mode_block(const Ctx&, int block);
-int plane_fft_forward_rows(Ctx&);                       // the transforms in pieces (rows of all planes / columns of one block)
-void plane_fft_forward_columns(Ctx&, const ModeBlock&);
-void plane_fft_inverse_columns(Ctx&, const ModeBlock&);
-int plane_fft_inverse_rows(Ctx&);
+int plane_fft_forward_rows(Ctx&, int z0 = 0, int nz = -1);                       // the transforms in pieces (rows of all planes / columns of one block)
+void plane_fft_forward_columns(Ctx&, const ModeBlock&, int z0 = 0, int nz = -1);
+void plane_fft_inverse_columns(Ctx&, const ModeBlock&, int z0 = 0, int nz = -1);
+int plane_fft_inverse_rows(Ctx&, int z0 = 0, int nz = -1);
 void launch_phi_halo_pack(Ctx&);
 // diag.hip
 constexpr int DIAG_SCRATCH = 1024 + 8;
@@ -218,6 +219,10 @@ struct Ctx {
   int shift = 0;               // planes the lattice moves per sweep in in-place mode (0 in A/B mode)
   int zchunk = 0;              // planes per bulk launch in in-place mode (shift >= zchunk + 1)
   int ab_zchunk = 0;           // two-buffer mode: planes per bulk launch of the sweep (0: one launch)
+  int bulk_yband = -1;         // two-buffer mode: the interior sweep takes bands of this many rows of EVERY plane, band after band, instead of
+                               // plane after plane (lbm_kernels.hip: bulk_row_of_block): the three uses of a phi row lie within the Infinity
+                               // Cache's reach.  -1: decided from the plane's traffic (bulk_dispatch), 0: plane after plane (ekpnp_tune
+                               // "bulk_yband", EKPNP_BULK_YBAND)
   bool merged_walls = true;    // launch-bound two-buffer lattices: plates and bulk in one launch (k_collide_all)
   // base pointer of lattice l's CURRENT state (plane zg = 0 is the ghost plane below)
   double* cur_base(int l) const {
@@ -275,6 +280,8 @@ struct Ctx {
                                    // > 1: the EDGE all-gather of block k runs on the comm stream beside the column pass of block k + 1
   int poisson_blocks = 0;          // single context (0: decided from the spectrum's size, poisson.hip: poisson_block_count): kx column blocks of the solve's middle passes (y forward, z solve, y inverse of one block back to
                                    // back, so that the block stays in the Infinity Cache between them; ekpnp_tune "poisson_blocks", EKPNP_POISSON_BLOCKS)
+  int poisson_zchunk = 0;          // single context, own transforms: planes per chunk of the row + column passes (rows and columns of one chunk back
+                                   // to back: the chunk is still in the Infinity Cache; 0 = whole passes; ekpnp_tune "poisson_zchunk", EKPNP_POISSON_ZCHUNK)
   double* phi_old = nullptr;       // PB relaxation state (ekpnp_pbe_begin/end)
   double* diag = nullptr;          // reduction scratch (DIAG_SCRATCH doubles)
   double* vwall = nullptr;         // {voltage, voltage, voltage2, voltage2}

@@ -301,7 +301,7 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
 }
 
 // row of the launch a workgroup works on (XCD-aware placement), or -1 when it is beyond the last row
-__device__ __forceinline__ int bulk_row_of_block(const int nrows, const int nxb, const int rchunk, int& xb) {
+__device__ __forceinline__ int bulk_row_of_block(const int nrows, const int nxb, const int rchunk_arg, int& xb, const int ny = 0) {
   // XCD-aware placement.  Workgroups are dealt round-robin over the 8 XCDs (bid % 8 picks the
   // XCD).  Each XCD is given runs of `rchunk` CONSECUTIVE x rows (and walks along x inside a row),
   // so that every one of the 27+27 direction streams is sequential per XCD instead of a 1-in-8
@@ -311,14 +311,23 @@ __device__ __forceinline__ int bulk_row_of_block(const int nrows, const int nxb,
   const int xcd = bid & 7, slot = bid >> 3;
   const int r = slot / nxb;
   xb = slot - r * nxb;
-  const int row = ((r / rchunk) * 8 + xcd) * rchunk + r % rchunk;
-  return row < nrows ? row : -1;
+  const int rchunk = rchunk_arg & 0xffff, yband = rchunk_arg >> 16;
+  int row = ((r / rchunk) * 8 + xcd) * rchunk + r % rchunk;
+  if (row >= nrows) return -1;
+  if (yband > 0) {
+    // y bands (A/B knob EKPNP_BULK_YBAND, k_collide_bulk only): the sweep takes band b (yband rows) of EVERY plane, then band
+    // b + 1, instead of plane after plane - between the three uses of a phi row (as z+1, z, z-1) lie one and two band-planes
+    // of traffic (118 / 237 MB at yband = 128 on 512 x 512 planes) instead of one and two planes (474 / 948 MB)
+    const int per_band = (nrows / ny) * yband, band = row / per_band, rem = row - band * per_band, z = rem / yband;
+    row = z * ny + band * yband + (rem - z * yband);
+  }
+  return row;
 }
 
 template <int NL, bool PULL, bool EPHI>
 __global__ void __launch_bounds__(64 * NL, EKPNP_BULK_MIN_WAVES) k_collide_bulk(const KArgs a, const int zl_begin, const int nrows, const int nxb, const int rchunk) {
   int xb;
-  const int row = bulk_row_of_block(nrows, nxb, rchunk, xb);
+  const int row = bulk_row_of_block(nrows, nxb, rchunk, xb, a.ny);
   if (row < 0) return;  // whole workgroup leaves together
   bulk_body<NL, PULL, EPHI>(a, zl_begin, row, xb);
 }
@@ -769,10 +778,20 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
   if (nrows <= 0) return;
   const int nxb = (c.p.nx + 63) / 64;
   static const int rchunk_env = std::getenv("EKPNP_BULK_RCHUNK") ? std::atoi(std::getenv("EKPNP_BULK_RCHUNK")) : 64;  // tuning knob
-  const int rchunk = rchunk_env < 1 ? 1 : rchunk_env;
+  int rchunk = rchunk_env < 1 ? 1 : (rchunk_env > 0xffff ? 0xffff : rchunk_env);
   // rows per XCD, rounded up to whole runs: the 8 XCDs together cover [0, 8*per_xcd) >= nrows
   const long long per_xcd = ((long long)nrows + 8LL * rchunk - 1) / (8LL * rchunk) * rchunk;
   dim3 g((unsigned)(8 * per_xcd * nxb)), b(64 * NL);
+  // y bands (bulk_row_of_block; two-buffer contexts only: the in-place sweep's launches must finish plane after plane).  The
+  // sweep of one PLANE moves nx ny x 1 808 B = 474 MB on 512 x 512 planes, 1.9 GB on 1024 x 1024 ones, so the phi row a
+  // workgroup reads as z + 1 has left the 256 MiB Infinity Cache long before it comes back as z and z - 1.  Taken in bands of
+  // 128 rows the re-reads find it there: bulk kernel 38.68 -> 38.40 ms on cfg3, 38.90 -> 38.43 ms on cfg5's 1024 x 1024 x 128
+  // slab (bands of 64 and 256 rows gain about half of that; profiles/r05c_ab_bulk_yband*.jsonl).  Same arithmetic per node,
+  // another order of the workgroups: same bits.  Default (-1): bands of 128 rows where a plane's sweep moves more than
+  // 192 MiB and NY is a multiple of 128; smaller planes (256 x 256: 90 - 118 MB) are within the cache's reach as they are.
+  int yband = c.bulk_yband;
+  if (yband < 0) yband = (size_t)c.p.nx * c.p.ny * (size_t)(NL * 27 * 16 + 80) > ((size_t)192 << 20) ? 128 : 0;
+  if (yband > 0 && yband < c.p.ny && !c.inplace && c.p.ny % yband == 0 && yband % rchunk == 0) rchunk |= yband << 16;
   const bool ephi = collide_takes_e_from_phi(c);
   if (c.streamed_state) {
     if (ephi) hipLaunchKernelGGL((k_collide_bulk<NL, false, (NL > 1)>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);

@@ -54,25 +54,32 @@ int plane_fft_setup(Ctx& c) {
 // The transforms in pieces, for the slab solve with mode blocks (own passes only; with rocFFT plans the 2-D transform is one
 // call, issued with the first / last piece): forward = rows of all planes, then the columns of block k; inverse = the columns
 // of block k, then the rows of all planes.
-int plane_fft_forward_rows(Ctx& c) {
+// (z0, nz: a run of the transform's planes, for the plane chunks of a single context's solve - "poisson_zchunk"; nz < 0: all)
+int plane_fft_forward_rows(Ctx& c, int z0, int nz) {
   if (!c.own_fft) return plane_fft_forward(c);
-  fft_x_forward(c.fft_in(), reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw, c.p.nx, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
+  if (nz < 0) { z0 = 0; nz = c.fft_nz; }
+  fft_x_forward(c.fft_in() + (size_t)z0 * c.plane, reinterpret_cast<double2*>(c.fft_spec()) + (size_t)z0 * c.p.ny * c.nxh, c.fft_tw, c.p.nx, c.nxh,
+                (long long)c.p.ny * nz, c.stream);
   note_launch(c, "k_fft_x_r2c");
   return EKPNP_OK;
 }
-void plane_fft_forward_columns(Ctx& c, const ModeBlock& b) {
+void plane_fft_forward_columns(Ctx& c, const ModeBlock& b, int z0, int nz) {
   if (!c.own_fft) return;
-  fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw + c.p.nx, c.p.ny, c.nxh, c.fft_nz, -1, c.stream, b.x0 / 8, b.bw / 8);
+  if (nz < 0) { z0 = 0; nz = c.fft_nz; }
+  fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()) + (size_t)z0 * c.p.ny * c.nxh, c.fft_tw + c.p.nx, c.p.ny, c.nxh, nz, -1, c.stream, b.x0 / 8, b.bw / 8);
   note_launch(c, "k_fft_y<-1>");
 }
-void plane_fft_inverse_columns(Ctx& c, const ModeBlock& b) {
+void plane_fft_inverse_columns(Ctx& c, const ModeBlock& b, int z0, int nz) {
   if (!c.own_fft) return;
-  fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()), c.fft_tw + c.p.nx, c.p.ny, c.nxh, c.fft_nz, +1, c.stream, b.x0 / 8, b.bw / 8);
+  if (nz < 0) { z0 = 0; nz = c.fft_nz; }
+  fft_y_launch(reinterpret_cast<double2*>(c.fft_spec()) + (size_t)z0 * c.p.ny * c.nxh, c.fft_tw + c.p.nx, c.p.ny, c.nxh, nz, +1, c.stream, b.x0 / 8, b.bw / 8);
   note_launch(c, "k_fft_y<1>");
 }
-int plane_fft_inverse_rows(Ctx& c) {
+int plane_fft_inverse_rows(Ctx& c, int z0, int nz) {
   if (!c.own_fft) return plane_fft_inverse(c);
-  fft_x_inverse(reinterpret_cast<const double2*>(c.fft_spec()), c.fft_out(), c.fft_tw, c.p.nx, c.nxh, (long long)c.p.ny * c.fft_nz, c.stream);
+  if (nz < 0) { z0 = 0; nz = c.fft_nz; }
+  fft_x_inverse(reinterpret_cast<const double2*>(c.fft_spec()) + (size_t)z0 * c.p.ny * c.nxh, c.fft_out() + (size_t)z0 * c.plane, c.fft_tw, c.p.nx, c.nxh,
+                (long long)c.p.ny * nz, c.stream);
   note_launch(c, "k_fft_x_c2r");
   return EKPNP_OK;
 }
@@ -1231,6 +1238,12 @@ int poisson_block_count(const Ctx& c) {
   if (want <= 0) want = (size_t)c.p.ny * c.nxh * (size_t)(c.p.nz - 2) * sizeof(double2) >= ((size_t)768 << 20) ? 3 : 1;
   const int gu = block_unit_groups(c), units = (c.nxh / 8 + gu - 1) / gu;
   return want > units ? units : want;
+}
+ModeBlock poisson_block_whole(const Ctx& c) {
+  ModeBlock b{};
+  b.x0 = 0;
+  b.bw = c.nxh;
+  return b;
 }
 ModeBlock poisson_block(const Ctx& c, int k) {
   ModeBlock b{};

@@ -570,6 +570,45 @@ def test_merged_wall_kernel_equals_separate_launches(pkg, O):
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+def test_band_order_of_the_sweep_changes_no_bit(pkg, O):
+    """ekpnp_tune "bulk_yband" (round 5): the interior sweep takes bands of 128 rows of every plane, band after band, instead of
+    plane after plane, so that a phi row's three uses (as z + 1, z, z - 1) lie within the Infinity Cache's reach (the default
+    on planes whose sweep moves more than 192 MiB: cfg3 - cfg5).  Another order of the workgroups, the same arithmetic per
+    node: every field must come out bit for bit the same - bands of 64 and 128 rows against plane order, one context
+    (separate bulk launch forced: small lattices use the merged kernel, which has no bands) and two slabs; and the band
+    order against the ORACLE."""
+    po = O.default_params(64, 256, 14)
+    po.pb_iterations = 10
+    outs = {}
+    start = None
+    for band in (0, 64, 128):
+        for nslabs in (1, 2):
+            with (pkg.Solver(_mirror(pkg, po)) if nslabs == 1 else pkg.Group(_mirror(pkg, po), 2, devices=[0, 0])) as s:
+                if nslabs == 1:
+                    s.tune("merged_walls", 0)
+                s.tune("bulk_yband", band)
+                s.initialization()
+                if start is None:
+                    start = O.perturb_fields(po, s.fields())
+                s.set_fields(start)
+                s.fast_Poisson(); s.init_equilibrium()
+                s.step(7)
+                outs[band, nslabs] = s.fields()
+    for key, f in outs.items():
+        for k in f:
+            # (one context and two slabs solve the z system in different elimination orders: each is compared with its own plane order)
+            assert np.isfinite(f[k]).all() and np.array_equal(outs[0, key[1]][k], f[k]), (key, k)
+    orc = O.Oracle(po)
+    try:
+        orc.initialization()
+        orc.set_fields(start)
+        orc.fast_poisson(); orc.init_equilibrium()
+        orc.step(7)
+        _assert_all([(7, O.rel_l2(outs[128, 1], orc.fields()))], name="band_order_vs_oracle")
+    finally:
+        orc.close()
+
+
 def test_in_place_mode_vs_oracle(pkg, O):
     po = O.default_params(20, 8, 140)
     po.pb_iterations = 10
@@ -1003,14 +1042,15 @@ def test_column_blocks_of_the_solve_are_bitwise_the_one_block_solve(pkg):
             s.tune("tri_partition", 2)
             s.set_field("c", cc); s.set_field("cn", cn)
             ref = None
-            for nb in (1, 0, 2, 3, 5, 11, 33, 200):
+            for nb, zc in ((1, 0), (0, 0), (2, 0), (3, 0), (5, 0), (11, 0), (33, 0), (200, 0), (1, 16), (3, 40), (1, 1000)):
                 s.tune("poisson_blocks", nb)
+                s.tune("poisson_zchunk", zc)  # (its measured A/B partner: rows + columns of one run of planes back to back)
                 s.fast_Poisson()
                 phi = s.get_field("phi")
                 if ref is None:
                     ref = phi
                     assert np.isfinite(ref).all() and np.abs(ref).max() > 1e-4
-                assert np.array_equal(ref, phi), f"poisson_blocks = {nb} changed phi on {shape}"
+                assert np.array_equal(ref, phi), f"poisson_blocks = {nb}, poisson_zchunk = {zc} changed phi on {shape}"
         del cc, cn
     # the time loop (the collide's fused right-hand side, lazy E, hipGraph replay) through three blocks and through one
     shape = (512, 512, 70)

@@ -15,9 +15,12 @@ import __graft_entry__ as G  # noqa: E402
 pkg = G.load_package()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 blocks = [1, 2, 3, 4, 6, 8, 11, 16, 33, 1]
+zchunks = [0]
 for a in sys.argv[1:]:
     if a.startswith("--blocks="):
         blocks = [int(v) for v in a.split("=", 1)[1].split(",")]
+    if a.startswith("--zchunks="):  # planes per chunk of the row + column passes ("poisson_zchunk"), 0 = whole passes
+        zchunks = [int(v) for v in a.split("=", 1)[1].split(",")]
 grids = args or ["512x512x512"]
 for g in grids:
     shape = tuple(int(v) for v in g.split("x"))
@@ -31,8 +34,9 @@ for g in grids:
     s.set_field("c", 0.01 * (1.0 + 0.1 * rng.standard_normal(zyx)))
     s.set_field("cn", 0.01 * (1.0 + 0.1 * rng.standard_normal(zyx)))
     ref = None
-    for nb in blocks:
+    for nb, zc in [(b, z) for z in zchunks for b in blocks]:
         s.tune("poisson_blocks", nb)
+        s.tune("poisson_zchunk", zc)
         for _ in range(3):
             s.fast_Poisson()
         s.synchronize()
@@ -46,7 +50,7 @@ for g in grids:
         if ref is None:
             ref = phi
         same = bool(np.array_equal(ref, phi))
-        print(json.dumps({"grid": g, "poisson_blocks": nb, "ms_per_solve": round(dt * 1e3, 4), "same_bits_as_one_block": same,
+        print(json.dumps({"grid": g, "poisson_blocks": nb, "poisson_zchunk": zc, "ms_per_solve": round(dt * 1e3, 4), "same_bits_as_one_block": same,
                           "phi_absmax": float(np.abs(phi).max())}), flush=True)
         del phi
     s.close()

@@ -219,7 +219,7 @@ struct Ctx {
   int shift = 0;               // planes the lattice moves per sweep in in-place mode (0 in A/B mode)
   int zchunk = 0;              // planes per bulk launch in in-place mode (shift >= zchunk + 1)
   int ab_zchunk = 0;           // two-buffer mode: planes per bulk launch of the sweep (0: one launch)
-  int bulk_yband = -1;         // two-buffer mode: the interior sweep takes bands of this many rows of EVERY plane, band after band, instead of
+  int bulk_yband = -1;         // the interior sweep (in place: each of its launches) takes bands of this many rows of EVERY plane, band after band, instead of
                                // plane after plane (lbm_kernels.hip: bulk_row_of_block): the three uses of a phi row lie within the Infinity
                                // Cache's reach.  -1: decided from the plane's traffic (bulk_dispatch), 0: plane after plane (ekpnp_tune
                                // "bulk_yband", EKPNP_BULK_YBAND)

@@ -782,7 +782,8 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
   // rows per XCD, rounded up to whole runs: the 8 XCDs together cover [0, 8*per_xcd) >= nrows
   const long long per_xcd = ((long long)nrows + 8LL * rchunk - 1) / (8LL * rchunk) * rchunk;
   dim3 g((unsigned)(8 * per_xcd * nxb)), b(64 * NL);
-  // y bands (bulk_row_of_block; two-buffer contexts only: the in-place sweep's launches must finish plane after plane).  The
+  // y bands (bulk_row_of_block; in-place contexts: inside each of the sweep's launches of `zchunk` planes - a launch writes only
+  // where no plane it reads lies, whatever the order of its workgroups).  The
   // sweep of one PLANE moves nx ny x 1 808 B = 474 MB on 512 x 512 planes, 1.9 GB on 1024 x 1024 ones, so the phi row a
   // workgroup reads as z + 1 has left the 256 MiB Infinity Cache long before it comes back as z and z - 1.  Taken in bands of
   // 128 rows the re-reads find it there: bulk kernel 38.68 -> 38.40 ms on cfg3, 38.90 -> 38.43 ms on cfg5's 1024 x 1024 x 128
@@ -791,7 +792,7 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
   // 192 MiB and NY is a multiple of 128; smaller planes (256 x 256: 90 - 118 MB) are within the cache's reach as they are.
   int yband = c.bulk_yband;
   if (yband < 0) yband = (size_t)c.p.nx * c.p.ny * (size_t)(NL * 27 * 16 + 80) > ((size_t)192 << 20) ? 128 : 0;
-  if (yband > 0 && yband < c.p.ny && !c.inplace && c.p.ny % yband == 0 && yband % rchunk == 0) rchunk |= yband << 16;
+  if (yband > 0 && yband < c.p.ny && c.p.ny % yband == 0 && yband % rchunk == 0) rchunk |= yband << 16;
   const bool ephi = collide_takes_e_from_phi(c);
   if (c.streamed_state) {
     if (ephi) hipLaunchKernelGGL((k_collide_bulk<NL, false, (NL > 1)>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);

@@ -594,6 +594,16 @@ def test_band_order_of_the_sweep_changes_no_bit(pkg, O):
                 s.fast_Poisson(); s.init_equilibrium()
                 s.step(7)
                 outs[band, nslabs] = s.fields()
+    pi = _mirror(pkg, po)
+    pi.in_place = 1  # in place: bands inside each of the sweep's launches of nzl / 4 planes
+    for band in (0, 64):
+        with pkg.Solver(pi) as s:
+            s.tune("bulk_yband", band)
+            s.initialization()
+            s.set_fields(start)
+            s.fast_Poisson(); s.init_equilibrium()
+            s.step(7)
+            outs[band, "in place"] = s.fields()
     for key, f in outs.items():
         for k in f:
             # (one context and two slabs solve the z system in different elimination orders: each is compared with its own plane order)

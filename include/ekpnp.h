@@ -272,6 +272,13 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
  * 2 = wherever it applies; the two solve the same system in a different elimination order (equal to rounding).
  * "tri_wide": 1 = 16 modes (wavefronts) per workgroup on columns of more than 256 rows (256-byte pieces of every row; 3 %
  * faster in isolation, default 0), same bits.
+ * "bulk_yband" (EKPNP_BULK_YBAND): the interior sweep takes bands of that many rows of EVERY plane, band after band, instead of
+ * plane after plane, so that the phi rows the collide reads three times (as z+1, z, z-1: E is formed from phi) are still in
+ * the 256 MiB Infinity Cache when they come back.  -1 (default) = bands of 128 rows where the sweep of one plane moves more
+ * than 192 MiB (cfg3: bulk kernel 38.69 -> 38.45 ms) and plane order elsewhere, 0 = plane order, n = bands of n rows (a
+ * multiple of 64 that divides NY; anything else is ignored).  Another order of the workgroups: same bits.
+ * "poisson_zchunk" (EKPNP_POISSON_ZCHUNK, default 0 = off): rows + columns of runs of that many planes back to back - the
+ * measured alternative to "poisson_blocks" (gains less); same bits.
  * "poisson_blocks" (EKPNP_POISSON_BLOCKS; single contexts on 512- / 1024-wide planes whose z solve is the partition solve):
  * the solve's three middle passes - y forward, z solve, y inverse - taken kx block by kx block, the three passes of one block
  * back to back, so that part of a block is still in the 256 MiB Infinity Cache when the next pass wants it.  0 (default) = the

@@ -32,8 +32,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as G  # noqa: E402
 
-SOLVER_KNOBS = (("tri_partition", (0, 1, 2)), ("batch_moments", (0, 1)), ("lazy_efield", (0, 1)), ("merged_walls", (0, 1)), ("tri_wide", (0, 1)), ("ab_zchunk", (0, 1, 3)))
-GROUP_KNOBS = (("edge_chunks", (1, 2, 3)), ("merged_faces", (0, 1)), ("lead_planes", (0, 1, 2)), ("batch_moments", (0, 1)), ("tri_partition", (0, 1, 2)), ("lazy_efield", (0, 1)))
+SOLVER_KNOBS = (("tri_partition", (0, 1, 2)), ("batch_moments", (0, 1)), ("lazy_efield", (0, 1)), ("merged_walls", (0, 1)), ("tri_wide", (0, 1)), ("bulk_yband", (-1, 0, 64)), ("poisson_blocks", (0, 1, 3)), ("poisson_zchunk", (0, 4)), ("ab_zchunk", (0, 1, 3)))
+GROUP_KNOBS = (("bulk_yband", (-1, 0, 64)), ("edge_chunks", (1, 2, 3)), ("merged_faces", (0, 1)), ("lead_planes", (0, 1, 2)), ("batch_moments", (0, 1)), ("tri_partition", (0, 1, 2)), ("lazy_efield", (0, 1)))
 TOL, TOL_U = 1e-9, 1e-7
 
 

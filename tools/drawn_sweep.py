@@ -19,8 +19,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as G  # noqa: E402
 
-SOLVER_KNOBS = (("tri_partition", (0, 1, 2)), ("batch_moments", (0, 1)), ("lazy_efield", (0, 1)), ("merged_walls", (0, 1)), ("tri_wide", (0, 1)))
-GROUP_KNOBS = (("edge_chunks", (1, 2, 3, 4)), ("merged_faces", (0, 1)), ("lead_planes", (0, 1, 2, 5)), ("batch_moments", (0, 1)), ("tri_partition", (0, 1, 2)),
+SOLVER_KNOBS = (("tri_partition", (0, 1, 2)), ("batch_moments", (0, 1)), ("lazy_efield", (0, 1)), ("merged_walls", (0, 1)), ("tri_wide", (0, 1)), ("bulk_yband", (-1, 0, 64)), ("poisson_blocks", (0, 1, 3)), ("poisson_zchunk", (0, 4)))
+GROUP_KNOBS = (("bulk_yband", (-1, 0, 64)), ("edge_chunks", (1, 2, 3, 4)), ("merged_faces", (0, 1)), ("lead_planes", (0, 1, 2, 5)), ("batch_moments", (0, 1)), ("tri_partition", (0, 1, 2)),
                ("lazy_efield", (0, 1)))
 
 
@@ -44,6 +44,12 @@ def main():
             po.Lx, po.Ly = po.nx * po.dx, po.ny * po.dy
             po.pb_iterations = 1  # (the reference's Picard damping diverges on channels taller than ~180 planes, DESIGN section 6: 3 sweeps already give phi ~ 1e3 .. 1e8 V and a run that blows up - in the oracle too; one sweep stays physical)
             nslabs = int(rng.integers(1, 7))
+        elif rng.random() < 0.25:  # wide in y: the band order of the sweep ("bulk_yband": 64 rows divide these NY), in place or not, slabs
+            po.ny = int(rng.choice([128, 256]))
+            po.nx = int(rng.choice([8, 16, 64]))
+            nslabs = int(rng.integers(1, 4))
+            po.nz = int(rng.integers(max(6, 4 * nslabs), 19))  # (a z slab holds at least 4 planes)
+            po.Lx, po.Ly, po.Lz = po.nx * po.dx, po.ny * po.dy, (po.nz - 1) * po.dz
         nl = po.n_lattices
         skip = () if nl == 4 else (("T",) if nl == 3 else ("T", "c", "cn", "phi", "E"))
         groups = {k: v for k, v in O.GROUPS.items() if k not in skip}
@@ -51,6 +57,8 @@ def main():
         for name, vals in (SOLVER_KNOBS if nslabs == 1 else GROUP_KNOBS):
             if rng.random() < 0.4:
                 knobs.append((name, int(rng.choice(vals))))
+        if po.ny % 128 == 0 and rng.random() < 0.7:  # the wide cases: bands on, and the separate bulk launch that has them
+            knobs = [kv for kv in knobs if kv[0] not in ("bulk_yband", "merged_walls")] + [("bulk_yband", 64)] + ([("merged_walls", 0)] if nslabs == 1 else [])
         tag = f"{seed}: {po.nx}x{po.ny}x{po.nz} nl={nl} ip={po.in_place} slabs={nslabs} steps={steps} knobs={knobs}"
         rec = {"seed": seed, "case": tag}
         try:
@@ -60,6 +68,13 @@ def main():
             orc.set_fields(start); orc.fast_poisson(); orc.init_equilibrium(); orc.step(steps)
             want, want_cur = orc.fields(), orc.current()
             orc.close()
+            if not all(np.isfinite(v).all() for v in want.values()):
+                # the reference's own Poisson-Boltzmann start-up diverges on this draw (tall channel): there is
+                # no finite answer to compare with - counted apart, not as a failure of either side
+                rec.update({"ok": True, "skipped": "the oracle's run is not finite (the reference's initialization diverges on this draw)"})
+                results.append(rec)
+                print("skip " + tag + "  the oracle's run is not finite", flush=True)
+                continue
             ctx = pkg.Solver(tp._mirror(pkg, po)) if nslabs == 1 else pkg.Group(tp._mirror(pkg, po), nslabs, devices=[0] * nslabs)
             with ctx as g:
                 for k, v in knobs:
@@ -82,7 +97,7 @@ def main():
         bad += not rec["ok"]
         worst = max(rec.get("rel_l2", {"-": float("nan")}).items(), key=lambda kv: kv[1]) if "rel_l2" in rec else ("error", rec.get("error"))
         print(("ok  " if rec["ok"] else "BAD ") + tag + f"  worst {worst[0]} {worst[1]}", flush=True)
-    summary = {"first_seed": first, "count": count, "failed": bad, "seconds": round(time.time() - t_all, 1),
+    summary = {"first_seed": first, "count": count, "failed": bad, "skipped_oracle_not_finite": sum(1 for r in results if "skipped" in r), "seconds": round(time.time() - t_all, 1),
                "worst_by_group": {k: max((r["rel_l2"].get(k, 0.0) for r in results if "rel_l2" in r), default=None) for k in O.GROUPS}}
     print(json.dumps(summary))
     if out_path:

@@ -969,7 +969,8 @@ def main():
                 if not slab_path and not p.in_place:
                     step_traffic = step_traffic_of(rec)
                 traffic_src = None if traffic is None else {"file": "profiles/pmc_traffic.json", "profiled_in": rec.get("round"),
-                               "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of that committed profile, NOT measured by this run"}
+                               "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of that committed profile, NOT measured by this run; counted where requests "
+                                       "leave the L2s - re-reads the 256 MiB Infinity Cache serves are included, so this bounds the HBM bytes from above"}
             except Exception:
                 traffic = None
         out = {
@@ -1009,6 +1010,8 @@ def main():
                 "placement": sol.placement_report(),
                 # the library's own row / column passes or rocFFT plans; ranks of this lattice on rank 0's device (> 1: a rehearsal)
                 "plane_transforms": sol.plane_transforms(),
+                # the cache-aware orders in effect (include/ekpnp.h: ekpnp_pass_order): rows per band of the interior sweep, kx blocks of the solve
+                "pass_order": sol.pass_order(),
                 # what RCCL was told through the environment (N>1; rehearsals add NCCL_HOSTID: ranks on one device pose as hosts)
                 "rccl_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES")} if slab_path else None,
                 "finite": finite,

@@ -332,6 +332,15 @@ extern "C" int ekpnp_plane_transforms(const ekpnp_ctx* ctx, int* own_passes, int
   return EKPNP_OK;
 }
 
+extern "C" int ekpnp_pass_order(const ekpnp_ctx* ctx, int* band_rows, int* poisson_blocks, int* poisson_zchunk) {
+  if (!ctx) return EKPNP_ERR_INVALID;
+  const Ctx& c = ctx->c;
+  if (band_rows) *band_rows = bulk_band_rows(c);
+  if (poisson_blocks) *poisson_blocks = poisson_block_count(c);
+  if (poisson_zchunk) *poisson_zchunk = !c.slab && c.own_fft && c.poisson_zchunk > 0 && c.poisson_zchunk < c.fft_nz ? c.poisson_zchunk : 0;
+  return EKPNP_OK;
+}
+
 // the population buffers inside their one allocation: A0 A1 A2 A3 B0 B1 B2 B3 (buffer-major; EKPNP_POP_ORDER=1, an
 // experiment of round 3: lattice-major A0 B0 A1 B1 ... - no difference, profiles/r03_direction_sweep.log)
 static void carve_arena(Ctx& c, void* base, size_t pitch) {

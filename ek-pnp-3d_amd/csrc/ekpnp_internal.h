@@ -157,6 +157,7 @@ void launch_init_fields(Ctx&);
 void launch_pbe(Ctx&);
 void launch_pbe_relax(Ctx&, double* phi_old, double omega);
 void launch_init_equilibrium(Ctx&);
+int bulk_band_rows(const Ctx&, int rchunk = 64);  // rows per band of the interior sweep in effect (0: plane after plane)
 void launch_collide_all(Ctx&);  // launch-bound lattices: plates and bulk in ONE launch (single two-buffer context)
 void launch_collide_bulk(Ctx&, int zl_begin, int zl_end);
 void launch_collide_bulk(Ctx&, const KArgs&, int zl_begin, int zl_end);

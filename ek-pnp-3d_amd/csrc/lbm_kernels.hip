@@ -772,6 +772,13 @@ void launch_init_equilibrium(Ctx& c) {
   }
 }
 
+// rows per band of the interior sweep in effect (0: plane after plane): Ctx::bulk_yband, or the rule above bulk_dispatch's launch
+int bulk_band_rows(const Ctx& c, int rchunk) {
+  int yband = c.bulk_yband;
+  if (yband < 0) yband = (size_t)c.p.nx * c.p.ny * (size_t)(c.p.n_lattices * 27 * 16 + 80) > ((size_t)192 << 20) ? 128 : 0;
+  return yband > 0 && yband < 0x7fff && yband < c.p.ny && c.p.ny % yband == 0 && yband % rchunk == 0 ? yband : 0;
+}
+
 template <int NL>
 static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
   const int nrows = (zl_end - zl_begin) * c.p.ny;
@@ -790,9 +797,7 @@ static void bulk_dispatch(Ctx& c, const KArgs& a, int zl_begin, int zl_end) {
   // slab (bands of 64 and 256 rows gain about half of that; profiles/r05c_ab_bulk_yband*.jsonl).  Same arithmetic per node,
   // another order of the workgroups: same bits.  Default (-1): bands of 128 rows where a plane's sweep moves more than
   // 192 MiB and NY is a multiple of 128; smaller planes (256 x 256: 90 - 118 MB) are within the cache's reach as they are.
-  int yband = c.bulk_yband;
-  if (yband < 0) yband = (size_t)c.p.nx * c.p.ny * (size_t)(NL * 27 * 16 + 80) > ((size_t)192 << 20) ? 128 : 0;
-  if (yband > 0 && yband < c.p.ny && c.p.ny % yband == 0 && yband % rchunk == 0) rchunk |= yband << 16;
+  rchunk |= bulk_band_rows(c, rchunk) << 16;
   const bool ephi = collide_takes_e_from_phi(c);
   if (c.streamed_state) {
     if (ephi) hipLaunchKernelGGL((k_collide_bulk<NL, false, (NL > 1)>), g, b, 0, c.stream, a, zl_begin, nrows, nxb, rchunk);

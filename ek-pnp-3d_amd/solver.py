@@ -113,6 +113,7 @@ def load_library():
         "ekpnp_phase_timing_get": (i32, [ctx, C.POINTER(i32), pd]),
         "ekpnp_poisson_stage_timing_get": (i32, [ctx, C.POINTER(i32), pd]),
         "ekpnp_plane_transforms": (i32, [ctx, C.POINTER(i32), C.POINTER(i32)]),
+        "ekpnp_pass_order": (i32, [ctx, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "ekpnp_device_bytes": (sz, [ctx]),
         "ekpnp_placement_report": (i32, [ctx, C.POINTER(i32), C.POINTER(i32), pd, i32]),
         "ekpnp_graph_state": (i32, [ctx]),
@@ -468,6 +469,13 @@ class Solver:
         own, n = C.c_int(), C.c_int()
         self._ck(self._L.ekpnp_plane_transforms(self._h, C.byref(own), C.byref(n)))
         return {"own_passes": bool(own.value), "ranks_on_device": n.value}
+
+    def pass_order(self) -> dict:
+        """the cache-aware orders in effect: {"band_rows": rows per band of the interior sweep (0: plane after plane),
+        "poisson_blocks": kx column blocks of the solve's middle passes, "poisson_zchunk": planes per chunk of its row + column passes}"""
+        b, nb, zc = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.ekpnp_pass_order(self._h, C.byref(b), C.byref(nb), C.byref(zc)))
+        return {"band_rows": b.value, "poisson_blocks": nb.value, "poisson_zchunk": zc.value}
 
     def poisson_stage_timing_get(self):
         """Slab contexts: (n solves, {"stage1", "edge_exchange", "stage2", "phi_exchange", "stage3"}: summed ms) of the

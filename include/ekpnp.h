@@ -406,6 +406,12 @@ int ekpnp_rccl_available(void);
  * and that with GPU_MAX_HW_QUEUES=1 both transforms run at full speed (42.8 / 44.0 ms per step).  The library prints this
  * advice once when ranks_on_device > 1 and the variable is unset; bench.py --single-device and the test workers set it. */
 int ekpnp_plane_transforms(const ekpnp_ctx* ctx, int* own_passes, int* ranks_on_device);
+/* The orders in effect that keep re-used rows in the Infinity Cache (ekpnp_tune "bulk_yband", "poisson_blocks", "poisson_zchunk";
+ * no reference counterpart: one thread per node in plane order, LBM.cu:474, and one 3-D transform, poisson.cu:86): *band_rows =
+ * rows per band of the interior sweep (0: plane after plane), *poisson_blocks = kx column blocks of a single context's solve
+ * (1: whole passes; always 1 on a slab), *poisson_zchunk = planes per chunk of its row + column passes (0: whole passes).
+ * Any pointer may be NULL. */
+int ekpnp_pass_order(const ekpnp_ctx* ctx, int* band_rows, int* poisson_blocks, int* poisson_zchunk);
 /* Failure semantics of the collective calls (no reference counterpart: the reference exit()s on any error,
  * LBM.cu:35-53).  Once RCCL is bound and the (small, host-side) team object exists, ekpnp_slab_attach_comm always
  * enters ncclCommInitRank, also on a rank whose stream / event set-up failed, so its peers return; the returns BEFORE

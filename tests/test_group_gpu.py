@@ -491,7 +491,7 @@ def test_interior_rank_at_cfg5_width_vs_oracle(pkg, O):
         assert abs(g.umax() - um) <= 1e-6 * abs(um) + 1e-30
 
 
-@pytest.mark.parametrize("shape", [(512, 512, 192), (1024, 1024, 64)])
+@pytest.mark.parametrize("shape", [(512, 512, 192), (1024, 1024, 32)])
 def test_cfg4_planes_decomposed_over_8_slabs_equal_one_context(pkg, O, shape):
     """cfg4's full 512 x 512 planes as a DECOMPOSITION over 8 slabs: 512 x 512 x 192 in 8 in-place slabs of 24 planes next
     to each other on the one GPU (rounds 2-3: 768 planes, round 4: 384; the far end of the index space is since round 4 the
@@ -500,9 +500,9 @@ def test_cfg4_planes_decomposed_over_8_slabs_equal_one_context(pkg, O, shape):
     instantiations run, the slab z solve's short-column form included) against the same lattice in ONE in-place context -
     same perturbed x-y-z dependent start, 5 steps.  The single context itself is pinned to the oracle at this width by
     test_full_size_vs_oracle[cfg3_width].
-    And cfg5's 1024 x 1024 planes over EIGHT slabs (six of them interior, as in cfg5@8) at a sixteenth of the height:
-    1024 x 1024 x 64 in 8 in-place slabs of 8 planes (own plane transforms, four modes per wavefront in the z solve,
-    302 MB halo messages) against one context."""
+    And cfg5's 1024 x 1024 planes over EIGHT slabs (six of them interior, as in cfg5@8) at the smallest height a slab
+    allows: 1024 x 1024 x 32 in 8 in-place slabs of 4 planes (own plane transforms, four modes per wavefront in the z
+    solve, 302 MB halo messages) against one context."""
     import importlib.util
     import torch
 

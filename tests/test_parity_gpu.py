@@ -587,6 +587,8 @@ def test_band_order_of_the_sweep_changes_no_bit(pkg, O):
                 if nslabs == 1:
                     s.tune("merged_walls", 0)
                 s.tune("bulk_yband", band)
+                if nslabs == 1:
+                    assert s.pass_order()["band_rows"] == band
                 s.initialization()
                 if start is None:
                     start = O.perturb_fields(po, s.fields())
@@ -1055,6 +1057,8 @@ def test_column_blocks_of_the_solve_are_bitwise_the_one_block_solve(pkg):
             for nb, zc in ((1, 0), (0, 0), (2, 0), (3, 0), (5, 0), (11, 0), (33, 0), (200, 0), (1, 16), (3, 40), (1, 1000)):
                 s.tune("poisson_blocks", nb)
                 s.tune("poisson_zchunk", zc)  # (its measured A/B partner: rows + columns of one run of planes back to back)
+                po_ = s.pass_order()  # (0 = the library decides: one block on a half spectrum of 0.15 - 0.43 GB; at most the 33 column groups)
+                assert po_["poisson_blocks"] == (1 if nb == 0 else min(nb, 33)) and po_["poisson_zchunk"] == (zc if zc < nz - 2 else 0), (nb, zc, po_)
                 s.fast_Poisson()
                 phi = s.get_field("phi")
                 if ref is None:

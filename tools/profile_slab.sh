@@ -10,7 +10,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/prof_slab_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 "$ROOT/bench.py" --force-slab --no-cpu-baseline --steps 8 --warmup 2 "$@" > "$OUT/trace.log" 2>&1 || { tail -5 "$OUT/trace.log"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 "$ROOT/bench.py" --force-slab --no-cpu-baseline --no-batch-ab --no-comm-ab --steps 8 --warmup 2 "$@" > "$OUT/trace.log" 2>&1 || { tail -5 "$OUT/trace.log"; exit 1; }
 T=$(find "$OUT" -name "*kernel_trace.csv" | head -1)
 S=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 python3 "$ROOT/tools/overlap_trace.py" "$T" > "$ROOT/gpurun_out/${TAG}_slab_overlap.json" || { echo "overlap_trace found no step: stale tool?"; exit 1; }

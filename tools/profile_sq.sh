@@ -11,7 +11,7 @@ OUT="$ROOT/gpurun_out/prof_sq_${TAG}_${LABEL}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 if [ "$#" -gt 0 ]; then ARGS="$*"; else ARGS="--workload cfg3"; fi
-BENCH="python3 $ROOT/bench.py $ARGS --no-cpu-baseline --steps 3 --warmup 1"
+BENCH="python3 $ROOT/bench.py $ARGS --no-cpu-baseline --no-batch-ab --no-comm-ab --steps 3 --warmup 1"  # (no after-the-fact A/B legs: they would dilute the per-kernel means)
 pass() {  # <dir> <counters...>
   local d="$1"; shift
   timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$d" -o pmc -- $BENCH > "$OUT/$d.log" 2>&1 || { tail -5 "$OUT/$d.log"; exit 1; }

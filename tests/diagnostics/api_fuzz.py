@@ -2,7 +2,7 @@
 """A stateful bug hunt, not a test: random SEQUENCES of the C ABI's calls on small lattices, mirrored call by call on the CPU
 oracle, fields compared whenever the sequence looks at them.
 
-    python tools/api_fuzz.py FIRST_SEED COUNT [out.json]
+    python tests/diagnostics/api_fuzz.py FIRST_SEED COUNT [out.json]
 
 What the straight-line parity tests do not reach is the library's bookkeeping between calls: is E still the central
 difference of phi (lazy E), is the right-hand side the collide left still the one fast_Poisson may use, does a captured
@@ -27,7 +27,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as G  # noqa: E402

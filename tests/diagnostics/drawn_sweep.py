@@ -2,7 +2,7 @@
 """A bug hunt, not a test: many drawn configurations (tests/test_parity_gpu.py::_drawn_case, wider: taller channels, up to 6
 slabs, random ekpnp_tune knobs that must not change a result) on the HIP path against the CPU oracle.
 
-    python tools/drawn_sweep.py FIRST_SEED COUNT [out.json]
+    python tests/diagnostics/drawn_sweep.py FIRST_SEED COUNT [out.json]
 
 Prints one line per case and a summary; exit code 1 if a case misses the suite's tolerance (TOL 1e-9, velocities 1e-7) or
 raises.  Test infrastructure: the oracle is the checker here, as in tests/."""
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as G  # noqa: E402

@@ -898,12 +898,12 @@ def test_random_call_sequences_vs_oracle(pkg, O):
     parity): 16 seeded random sequences of the C ABI's calls - step(n), the split pair, fast_Poisson alone, get_field, set_field
     of E / phi / c / cn / moments mid-run, init_equilibrium mid-run, ekpnp_tune, ekpnp_field_device_ptr, ekpnp_bind_field with
     device writes, ekpnp_invalidate_rhs, checkpoints into a new context of the other population mode or a group of slabs -
-    mirrored call by call on the oracle (tools/api_fuzz.py ran 600 of them once: profiles/r05b_api_fuzz_600.json)."""
+    mirrored call by call on the oracle (tests/diagnostics/api_fuzz.py ran 600 of them once: profiles/r05b_api_fuzz_600.json)."""
     import importlib.util
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("api_fuzz", os.path.join(root, "tools", "api_fuzz.py"))
+    spec = importlib.util.spec_from_file_location("api_fuzz", os.path.join(root, "tests", "diagnostics", "api_fuzz.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     me = sys.modules[__name__]

@@ -315,7 +315,7 @@ __device__ __forceinline__ int bulk_row_of_block(const int nrows, const int nxb,
   int row = ((r / rchunk) * 8 + xcd) * rchunk + r % rchunk;
   if (row >= nrows) return -1;
   if (yband > 0) {
-    // y bands (A/B knob EKPNP_BULK_YBAND, k_collide_bulk only): the sweep takes band b (yband rows) of EVERY plane, then band
+    // y bands (k_collide_bulk only; bulk_band_rows() decides, ekpnp_tune "bulk_yband"): the sweep takes band b (yband rows) of EVERY plane, then band
     // b + 1, instead of plane after plane - between the three uses of a phi row (as z+1, z, z-1) lie one and two band-planes
     // of traffic (118 / 237 MB at yband = 128 on 512 x 512 planes) instead of one and two planes (474 / 948 MB)
     const int per_band = (nrows / ny) * yband, band = row / per_band, rem = row - band * per_band, z = rem / yband;

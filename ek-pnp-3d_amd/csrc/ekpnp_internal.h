@@ -32,6 +32,20 @@ __host__ __device__ constexpr int ez_of(int d) {
   return t[d];
 }
 __host__ __device__ constexpr int opp_of(int d) { return d == 0 ? 0 : ((d & 1) ? d + 1 : d - 1); }
+// Slot of direction d inside a population tile ([Q][64] doubles), round 5: the 27 directions ordered by (c_z, c_y, c_x)
+// instead of the reference's numbering, so that the three directions a destination row pulls from ONE source row (same c_y,
+// c_z) are 1.5 KB of neighbours and the nine a destination plane pulls from one source plane are 4.6 KB - bulk kernel 38.69 -
+// 38.87 -> 38.62 - 38.71 ms on cfg3 (alternating legs on one box, profiles/r05g_ab_grouped_slots.log; round 1's copy probe had
+// priced a scattered numbering at 0.35 %).  The numbering of the ARITHMETIC (d, opp_of, the order of every sum) is the
+// reference's as before: only where a population lies in its tile changed - and with it the population part of the
+// checkpoint files, hence their new format id "EKPNPCK2".  EKPNP_SLOT_BY_DIRECTION builds the A/B partner (slot = d).
+__host__ __device__ constexpr int slot_of(int d) {
+#ifdef EKPNP_SLOT_BY_DIRECTION
+  return d;
+#else
+  return (ez_of(d) + 1) * 9 + (ey_of(d) + 1) * 3 + (ex_of(d) + 1);
+#endif
+}
 __host__ __device__ constexpr double w_of(int d) {
   return d == 0 ? 8.0 / 27.0 : d <= 6 ? 2.0 / 27.0 : d <= 18 ? 1.0 / 54.0 : 1.0 / 216.0;  // LBM.h:109-112
 }
@@ -46,8 +60,8 @@ __host__ __device__ constexpr int dn_dir(int k) {
   return t[k];
 }
 
-// Population layout (one array per lattice): [zg][y][x/64][Q][64] - a TILE holds the 27 populations
-// of 64 consecutive x nodes (13.8 KB), a row is ceil(nx/64) tiles, plane zg = 0 / nzl+1 are the
+// Population layout (one array per lattice): [zg][y][x/64][Q slots][64] - a TILE holds the 27 populations
+// of 64 consecutive x nodes (13.8 KB; direction d in slot slot_of(d), above), a row is ceil(nx/64) tiles, plane zg = 0 / nzl+1 are the
 // ghost planes.  The bulk kernel's wave writes ONE contiguous tile and pulls from the tiles of 9
 // neighbour rows; with the direction-major layout [Q][zg][y][x] it touched 27 + 27 streams that
 // lie gigabytes apart (pure-copy ceiling of the two shapes on one box: 5.95 vs 5.48 TB/s,

@@ -283,7 +283,7 @@ static_assert(sizeof(CkptHeader) == 64, "checkpoint header layout");
 
 int io_ckpt_write_header(Ctx& c, FILE* f, int z0, int nzl, int with_ghosts, double time) {
   CkptHeader h{};
-  std::memcpy(h.magic, "EKPNPCK1", 8);
+  std::memcpy(h.magic, "EKPNPCK2", 8);
   h.nx = c.p.nx; h.ny = c.p.ny; h.nz = c.p.nz; h.z0 = z0; h.nzl = nzl; h.nfields = EKPNP_NFIELDS;
   h.nl = c.p.n_lattices; h.streamed_state = c.streamed_state ? 1 : 0; h.with_ghosts = with_ghosts;
   h.time = time;
@@ -322,7 +322,7 @@ int io_ckpt_populations(Ctx& c, FILE* f, int l, int with_ghosts, int dir) {
 }
 
 int io_ckpt_check_header(Ctx& c, const CkptHeader& h, int z0, int nzl) {
-  if (std::memcmp(h.magic, "EKPNPCK1", 8) != 0) return fail(c, "not an EKPNPCK1 checkpoint file");
+  if (std::memcmp(h.magic, "EKPNPCK2", 8) != 0) return fail(c, "not an EKPNPCK2 checkpoint file");
   if (h.nx != c.p.nx || h.ny != c.p.ny || h.nz != c.p.nz || h.nfields != EKPNP_NFIELDS || h.nl != c.p.n_lattices)
     return fail(c, "checkpoint was written for a different lattice");
   if (h.z0 != z0 || h.nzl != nzl) return fail(c, "checkpoint holds other planes than this context / group owns");
@@ -362,7 +362,7 @@ extern "C" int ekpnp_load_checkpoint(ekpnp_ctx* ctx, const char* path, double* t
   FILE* f = std::fopen(path, "rb");
   if (!f) return fail(c, "cannot open checkpoint file");
   CkptHeader h{};
-  int rc = std::fread(&h, sizeof h, 1, f) == 1 ? io_ckpt_check_header(c, h, c.z0, c.nzl) : fail(c, "not an EKPNPCK1 checkpoint file");
+  int rc = std::fread(&h, sizeof h, 1, f) == 1 ? io_ckpt_check_header(c, h, c.z0, c.nzl) : fail(c, "not an EKPNPCK2 checkpoint file");
   if (rc == EKPNP_OK && c.slab && c.nranks > 1 && !h.with_ghosts)
     rc = fail(c, "a slab context loads its own per-rank checkpoint (with ghost planes); whole-lattice files go through ekpnp_group_load_checkpoint");
   if (rc == EKPNP_OK && !c.slab && h.with_ghosts) rc = fail(c, "this is a slab's per-rank checkpoint");

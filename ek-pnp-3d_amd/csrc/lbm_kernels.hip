@@ -193,7 +193,7 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
         return;
       }
     }
-    const double* rowp = src + ((long long)(zg - cz) * a.ny + ys[cy + 1]) * a.rowstride + d * 64;
+    const double* rowp = src + ((long long)(zg - cz) * a.ny + ys[cy + 1]) * a.rowstride + slot_of(d) * 64;
 #ifdef EKPNP_NT_LOADS  // A/B partner: non-temporal loads (every population is pulled exactly once) LOSE 3 %, profiles/r02_sweep_nt_loads.log
     f[d] = __builtin_nontemporal_load(rowp + xo[cx + 1]);
 #else
@@ -270,9 +270,9 @@ __device__ __forceinline__ void bulk_body(const KArgs& a, const int zl_begin, co
     // non-temporal: the populations written here are not read again before the next step
     // (+1 % on cfg3, profiles/r01_sweep_libs.log); EKPNP_PLAIN_STORES builds the A/B partner
 #ifdef EKPNP_PLAIN_STORES
-    if (act) dst[d * 64] = v;
+    if (act) dst[slot_of(d) * 64] = v;
 #else
-    if (act) __builtin_nontemporal_store(v, dst + d * 64);
+    if (act) __builtin_nontemporal_store(v, dst + slot_of(d) * 64);
 #endif
     if constexpr (EDGE && ez_of(d) != 0) {
       // ... and one that leaves through the face goes into the send buffer as well (what k_halo_pack would copy there)
@@ -364,7 +364,7 @@ __device__ __forceinline__ void gather(const KArgs& a, const int lat, const doub
         return;
       }
     }
-    f[d] = src[((long long)zs * a.ny + ys[cy + 1]) * a.rowstride + d * 64 + pop_xoff(xs[cx + 1])];
+    f[d] = src[((long long)zs * a.ny + ys[cy + 1]) * a.rowstride + slot_of(d) * 64 + pop_xoff(xs[cx + 1])];
   });
 }
 
@@ -380,7 +380,7 @@ __device__ __forceinline__ void wall_scalar_pops(const KArgs& a, int lat, const 
     const long long o = ((long long)zg * a.ny + y) * a.rowstride + pop_xoff(x);
     static_for<0, Q, 1>([&](auto ic) {
       constexpr int d = decltype(ic)::value;
-      const double v = src[opp_of(d) * 64 + o];
+      const double v = src[slot_of(opp_of(d)) * 64 + o];
       f[d] = (lat == 3) ? (-v + 2.0 * TH_wall * w_of(d)) : v;
     });
   }
@@ -528,7 +528,7 @@ __device__ __forceinline__ void wall_body(const KArgs& a, const int top, const i
         constexpr int sgn = (ex_of(d) > 0 || d == 3) ? 1 : (ex_of(d) < 0 ? -1 : 0);  // LBM.cu:1902-1927
         if constexpr (sgn != 0) v = v + sgn * (a.uw_multi * w_of(d));
       }
-      if (act) dst[d * 64 + orow] = v;
+      if (act) dst[slot_of(d) * 64 + orow] = v;
       if constexpr (ez_of(d) != 0) {
         if (hout && act && (ez_of(d) > 0) == (top != 0)) hout[(long long)halo_slot(d) * a.plane + hnode] = v;
       }
@@ -540,7 +540,7 @@ __device__ __forceinline__ void wall_body(const KArgs& a, const int top, const i
     double* __restrict__ dst = a.B[lat];
     auto store = [&](auto ic, double v) {
       constexpr int d = decltype(ic)::value;
-      if (act) dst[d * 64 + orow] = v;
+      if (act) dst[slot_of(d) * 64 + orow] = v;
       if constexpr (ez_of(d) != 0) {
         if (hout && act && (ez_of(d) > 0) == (top != 0)) hout[((long long)lat * 9 + halo_slot(d)) * a.plane + hnode] = v;
       }
@@ -610,7 +610,7 @@ __global__ void k_ghost_wrap(double* p0, double* p1, double* p2, double* p3, int
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
   if (x >= g.nx) return;
   double* pp[MAXL] = {p0, p1, p2, p3};
-  const int du = up_dir(k) * 64, dd = dn_dir(k) * 64;
+  const int du = slot_of(up_dir(k)) * 64, dd = slot_of(dn_dir(k)) * 64;
   for (int l = 0; l < nl; ++l) {
     double* p = pp[l];
     p[g.at(0, y, x) + du] = p[g.at(g.nzl, y, x) + du];      // ghost below <- top plane
@@ -626,8 +626,8 @@ __global__ void k_halo_pack(const double* p0, const double* p1, const double* p2
   const double* pp[MAXL] = {p0, p1, p2, p3};
   for (int l = 0; l < nl; ++l) {
     const double* p = pp[l];
-    send_up[((long long)l * 9 + k) * plane + i] = p[g.at(g.nzl, y, x) + up_dir(k) * 64];
-    send_dn[((long long)l * 9 + k) * plane + i] = p[g.at(1, y, x) + dn_dir(k) * 64];
+    send_up[((long long)l * 9 + k) * plane + i] = p[g.at(g.nzl, y, x) + slot_of(up_dir(k)) * 64];
+    send_dn[((long long)l * 9 + k) * plane + i] = p[g.at(1, y, x) + slot_of(dn_dir(k)) * 64];
   }
 }
 
@@ -642,8 +642,8 @@ __global__ void k_halo_pack_stage(const double* s0, const double* s1, const doub
   const long long plane = (long long)g.nx * g.ny, i = (long long)y * g.nx + x;
   const double* ss[MAXL] = {s0, s1, s2, s3};
   for (int l = 0; l < nl; ++l) {
-    send_up[((long long)l * 9 + k) * plane + i] = ss[l][g.at(1, y, x) + up_dir(k) * 64];  // last plane
-    send_dn[((long long)l * 9 + k) * plane + i] = ss[l][g.at(0, y, x) + dn_dir(k) * 64];  // first plane
+    send_up[((long long)l * 9 + k) * plane + i] = ss[l][g.at(1, y, x) + slot_of(up_dir(k)) * 64];  // last plane
+    send_dn[((long long)l * 9 + k) * plane + i] = ss[l][g.at(0, y, x) + slot_of(dn_dir(k)) * 64];  // first plane
   }
 }
 
@@ -668,8 +668,8 @@ __global__ void k_halo_unpack(double* p0, double* p1, double* p2, double* p3, in
   double* pp[MAXL] = {p0, p1, p2, p3};
   for (int l = 0; l < nl; ++l) {
     double* p = pp[l];
-    p[g.at(0, y, x) + up_dir(k) * 64] = recv_lo[((long long)l * 9 + k) * plane + i];
-    p[g.at(g.nzl + 1, y, x) + dn_dir(k) * 64] = recv_hi[((long long)l * 9 + k) * plane + i];
+    p[g.at(0, y, x) + slot_of(up_dir(k)) * 64] = recv_lo[((long long)l * 9 + k) * plane + i];
+    p[g.at(g.nzl + 1, y, x) + slot_of(dn_dir(k)) * 64] = recv_hi[((long long)l * 9 + k) * plane + i];
   }
 }
 
@@ -729,7 +729,7 @@ __global__ void k_init_equilibrium(KArgs a) {
     equilibrium(a, m, ux + k * Ex, uy + k * Ey, uz + k * Ez, eq);
     double* dst = a.B[lat];
 #pragma unroll
-    for (int d = 0; d < Q; ++d) dst[d * 64 + o] = eq[d];
+    for (int d = 0; d < Q; ++d) dst[slot_of(d) * 64 + o] = eq[d];
   });
 }
 

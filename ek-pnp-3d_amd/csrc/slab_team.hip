@@ -1289,7 +1289,7 @@ extern "C" int ekpnp_group_read_state(ekpnp_group* g, const char* path, double* 
   return EKPNP_OK;
 }
 
-// whole-lattice EKPNPCK1 checkpoint (fields + post-collision populations): the file a single
+// whole-lattice EKPNPCK2 checkpoint (fields + post-collision populations): the file a single
 // context writes with ekpnp_save_checkpoint; loading continues the run bit for bit
 extern "C" int ekpnp_group_save_checkpoint(ekpnp_group* g, const char* path) {
   NEEDLIVEGROUP(g);
@@ -1320,7 +1320,7 @@ extern "C" int ekpnp_group_load_checkpoint(ekpnp_group* g, const char* path, dou
   if (!f) { T.err = "cannot open checkpoint file"; return EKPNP_ERR_INVALID; }
   const int n = (int)T.m.size();
   CkptHeader h{};
-  if (std::fread(&h, sizeof h, 1, f) != 1) { std::fclose(f); T.err = "not an EKPNPCK1 checkpoint file"; return EKPNP_ERR_INVALID; }
+  if (std::fread(&h, sizeof h, 1, f) != 1) { std::fclose(f); T.err = "not an EKPNPCK2 checkpoint file"; return EKPNP_ERR_INVALID; }
   rc = io_ckpt_check_header(S(T, 0), h, 0, S(T, 0).p.nz);
   if (rc) T.err = S(T, 0).err;
   if (rc == EKPNP_OK && h.with_ghosts) { T.err = "this is a slab's per-rank checkpoint, not a whole-lattice one"; rc = EKPNP_ERR_INVALID; }

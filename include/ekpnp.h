@@ -220,7 +220,8 @@ int ekpnp_read_state(ekpnp_ctx* ctx, const char* path, double* time);
 
 /* Full checkpoint (no reference counterpart; the reference can only restart from fields): the 11
  * fields AND the post-collision populations of every lattice, raw FP64 behind a 64-byte header
- * "EKPNPCK1".  Loading it continues the interrupted run bit for bit, in a two-buffer or an in-place
+ * "EKPNPCK2" (round 5: the directions inside a population tile are ordered by (c_z, c_y, c_x), slot = 9 (c_z + 1) + 3 (c_y + 1)
+ * + (c_x + 1); files of the earlier layout, "EKPNPCK1", are refused).  Loading it continues the interrupted run bit for bit, in a two-buffer or an in-place
  * context alike (512^3 x 4 lattices: 128 GB).  A single context writes / reads a whole-lattice file,
  * interchangeable with ekpnp_group_save_checkpoint / _load_checkpoint; a slab context on its own
  * writes / reads a per-rank file that includes its two ghost planes. */

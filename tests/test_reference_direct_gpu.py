@@ -407,14 +407,18 @@ _C27 = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 
 
 
 def _checkpoint_populations(path, p):
-    """[lattice][z][y][x][27]: the post-collision populations of a whole-lattice EKPNPCK1 file (layout documented
-    in include/ekpnp.h / io.hip: 64-byte header, 11 fields, then per lattice NZ planes of [y][x/64][27][64])."""
+    """[lattice][z][y][x][27]: the post-collision populations of a whole-lattice EKPNPCK2 file (layout documented
+    in include/ekpnp.h / io.hip: 64-byte header, 11 fields, then per lattice NZ planes of [y][x/64][27 slots][64])."""
     nx, ny, nz, nl = p.nx, p.ny, p.nz, p.n_lattices
     tiles = (nx + 63) // 64
     raw = np.fromfile(path, dtype=np.float64, offset=64)
     nf = 11 * nx * ny * nz
     pops = raw[nf:].reshape(nl, nz, ny, tiles, 27, 64)
     assert raw.size == nf + pops.size
+    # since round 5 ("EKPNPCK2") direction d lies in slot 9 (c_z + 1) + 3 (c_y + 1) + (c_x + 1) of its tile
+    slot = [9 * (cz + 1) + 3 * (cy + 1) + (cx + 1) for cx, cy, cz in _C27]
+    assert sorted(slot) == list(range(27))
+    pops = pops[:, :, :, :, slot, :]
     return np.moveaxis(pops, 4, 5).reshape(nl, nz, ny, tiles * 64, 27)[:, :, :, :nx, :]
 
 

@@ -2,14 +2,14 @@
 
 Round 4 shipped two empty overlap profiles that README / DESIGN quoted as evidence.  The trace tools
 have their own test since (tests/test_tools_cpu.py); this one covers the other half: a path written between backticks in
-DESIGN.md, README.md, INTEGRATION.md or profiles/README.md - a profile, a test, a tool, a source file - must be there.
+DESIGN.md, DESIGN_HISTORY.md, README.md, INTEGRATION.md or profiles/README.md - a profile, a test, a tool, a source file - must be there.
 Built artefacts (git-ignored binaries the documents name beside their sources) are the only exceptions, and only when the
 source they are built from exists."""
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOCS = ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"))
+DOCS = ("DESIGN.md", "DESIGN_HISTORY.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"))
 TOKEN = re.compile(r"`([A-Za-z0-9_./\-]+)`")
 DIRS = ("profiles/", "tests/", "tools/", "oracle/", "include/", "examples/", "ek-pnp-3d_amd/", "csrc/")
 PROFILE_NAME = re.compile(r"r0\d[a-z]?_[A-Za-z0-9_.\-]+\.(json|jsonl|csv|log|txt)$")

@@ -58,7 +58,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(build())
+        # EKPNP_ORACLE_LIBRARY: another build of the same source - the AddressSanitizer / UBSan build of `make asan`
+        # (tests/test_oracle_cpu.py::test_oracle_under_sanitizers runs a child process with it)
+        named = os.environ.get("EKPNP_ORACLE_LIBRARY")
+        L = C.CDLL(named if named else build())
         L.oracle_default_params.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
         L.oracle_create.restype = C.c_void_p
         L.oracle_create.argtypes = [C.POINTER(Params), C.c_int]

@@ -497,3 +497,75 @@ def test_golden_G8_asymmetric_physics(O, grid):
         o.step_shifts(g["a2_shifts"][1 + done : 1 + mark])
         done = mark
         _check_race_aware(O, o, sub(o.fields()), {k: g[f"a2_step{mark}_{k}"] for k in O.FIELDS}, ys, f"perturbed step {mark}")
+
+
+_SANITIZED_RUN = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle as O
+h = hashlib.sha256()
+for grid, nl, uw in (((16, 12, 17), 4, 0.0), ((10, 6, 9), 3, 0.0), ((12, 4, 8), 1, 0.0), ((14, 6, 11), 4, 0.02)):
+    p = O.default_params(*grid)
+    p.pb_iterations, p.n_lattices, p.uw = 15, nl, uw
+    if nl < 4:
+        p.Ra = 0.0
+    if nl == 1:
+        p.chargeinf, p.TH, p.exf = 0.0, 0.0, 1e9
+    o = O.Oracle(p)
+    o.threads = O.set_threads(2)
+    o.initialization()
+    o.set_fields(O.perturb_fields(p, o.fields()))
+    o.fast_poisson()
+    o.init_equilibrium()
+    o.step(3)
+    o.stream_collide_save()
+    o.fast_poisson()
+    vals = (o.current(), o.umax())
+    f = o.fields()
+    assert all(np.isfinite(v).all() for v in f.values()) and all(np.isfinite(v) for v in vals)
+    for k in sorted(f):
+        h.update(np.ascontiguousarray(f[k]).tobytes())
+    o.close()
+print("SHA", h.hexdigest())
+"""
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """the reference has no sanitizer run (and one real race, LBM.cu:664-667 vs 1711-1714); the CPU oracle
+    - the checker every parity test leans on - runs here once under AddressSanitizer + UndefinedBehaviorSanitizer (`make -C
+    oracle asan`) on four small cases (4 / 3 / 1 lattices, a moving wall, a grid with an even plane count): no report, and the
+    same bits as the ordinary build.  A child process: the sanitizer runtime has to be in the process before python starts."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    odir = os.path.join(root, "oracle")
+
+    def runtime(name):
+        pth = subprocess.run(["gcc", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+        return pth if os.path.isabs(pth) and os.path.exists(pth) else None
+
+    asan, ubsan = runtime("libasan.so"), runtime("libubsan.so")
+    if asan is None:
+        pytest.skip("this gcc has no AddressSanitizer runtime")
+    subprocess.check_call(["make", "-s", "-C", odir, "asan"])
+    subprocess.check_call(["make", "-s", "-C", odir])
+    script = tmp_path / "run.py"
+    script.write_text(_SANITIZED_RUN)
+
+    def run(extra_env):
+        env = dict(os.environ, OMP_NUM_THREADS="2", **extra_env)
+        r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        return r.returncode, r.stdout, r.stderr
+
+    rc, out, err = run({"EKPNP_ORACLE_LIBRARY": os.path.join(odir, "libekpnp_oracle_asan.so"),
+                        "LD_PRELOAD": asan + ((" " + ubsan) if ubsan else ""),
+                        "ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1:abort_on_error=0",  # (python itself leaks by design)
+                        "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"})
+    assert rc == 0, err[-3000:]
+    assert "runtime error" not in err and "AddressSanitizer" not in err, err[-3000:]
+    rc2, out2, err2 = run({})
+    assert rc2 == 0, err2[-3000:]
+    sha = [ln for ln in out.splitlines() if ln.startswith("SHA")]
+    assert sha and sha == [ln for ln in out2.splitlines() if ln.startswith("SHA")]

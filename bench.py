@@ -186,9 +186,10 @@ COMM_AB_LEGS = (  # (label, [(knob, value) ...]) - what ONE GPU cannot decide (V
     ("lead_planes=0", [("lead_planes", 0)]),
     ("edge_chunks=4", [("edge_chunks", 4)]),
     ("edge_chunks=4 comm_cus=8", [("edge_chunks", 4), ("comm_cus", 8)]),
+    ("edge_p2p=1", [("edge_p2p", 1)]),  # the EDGE gather as direct send / receive pairs with every peer instead of ncclAllGather
 )
 AB_DEFAULTS = {"inline_exchanges": ("EKPNP_INLINE_EXCHANGES", 1), "comm_cus": ("EKPNP_COMM_CUS", 0), "lead_planes": ("EKPNP_SLAB_LEAD_PLANES", 2),
-               "edge_chunks": ("EKPNP_EDGE_CHUNKS", 1)}
+               "edge_chunks": ("EKPNP_EDGE_CHUNKS", 1), "edge_p2p": ("EKPNP_EDGE_P2P", 0)}
 
 
 def ab_baseline() -> dict:

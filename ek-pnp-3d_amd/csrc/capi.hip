@@ -130,7 +130,7 @@ extern "C" int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value) {
   if (!ctx || !knob) return EKPNP_ERR_INVALID;
   Ctx& c = ctx->c;
   // the transport's own knobs first (an attached slab; the members of an in-process group are tuned through ekpnp_group_tune)
-  if (c.team && (std::strcmp(knob, "inline_exchanges") == 0 || std::strcmp(knob, "comm_cus") == 0)) return team_ctx_tune(c, knob, value);
+  if (c.team && (std::strcmp(knob, "inline_exchanges") == 0 || std::strcmp(knob, "comm_cus") == 0 || std::strcmp(knob, "edge_p2p") == 0)) return team_ctx_tune(c, knob, value);
   return ctx_tune(c, knob, value);
 }
 

@@ -117,6 +117,7 @@ struct Team {
   // knobs (environment at creation, ekpnp_tune / ekpnp_group_tune later; the same on every rank)
   bool inline_x = true;   // EKPNP_INLINE_EXCHANGES: the EDGE and PHI exchanges of an RCCL team on the compute stream itself
   int comm_cus = 0;       // EKPNP_COMM_CUS: compute units kept free of the slab's own kernels
+  bool edge_p2p = false;  // EKPNP_EDGE_P2P: the EDGE all-gather of an RCCL team as direct ncclSend / ncclRecv pairs with every peer
   bool comm_strict = false;
   double t = 0.0;
   std::string err;
@@ -233,12 +234,30 @@ static int exchange_begin(Team& T, int x, int blk = 0) {
     }
   }
   if (T.kind == EKPNP_TRANSPORT_RCCL) {
+    if (x == X_EDGE && T.edge_p2p) {  // a rank's own piece of the gather: a device copy ahead of the sends, same stream
+      for (int i = 0; i < n; ++i) {
+        Ctx& c = S(T, i);
+        if ((rc = use(T, i))) return rc;
+        const ModeBlock mb = mode_block(c, blk);
+        THIP(T, hipMemcpyAsync(c.edge_all + mb.all_off + (size_t)c.rank * mb.doubles, c.edge_local + mb.local_off, mb.doubles * sizeof(double), hipMemcpyDeviceToDevice, xs(i)));
+      }
+    }
     TNCCL(T, T.nc->GroupStart());
     for (int i = 0; i < n; ++i) {
       Ctx& c = S(T, i);
       if ((rc = use(T, i))) { (void)T.nc->GroupEnd(); return rc; }
       ncclResult_t r = ncclSuccess;
-      if (x == X_EDGE) {
+      if (x == X_EDGE && T.edge_p2p) {
+        // the same gather as one direct send / receive pair per peer: on xGMI every peer is one hop away over a link of its
+        // own, so a rank's piece goes out on all links at once instead of travelling round a ring (A/B partner of the
+        // ncclAllGather below; the pieces land where it puts them - rank q's at [q] of the block -, hence the same bits)
+        const ModeBlock mb = mode_block(c, blk);
+        for (int q = 0; q < T.nranks && r == ncclSuccess; ++q) {
+          if (q == c.rank) continue;
+          r = T.nc->Send(c.edge_local + mb.local_off, mb.doubles, ncclDouble, q, T.comm[i], xs(i));
+          if (r == ncclSuccess) r = T.nc->Recv(c.edge_all + mb.all_off + (size_t)q * mb.doubles, mb.doubles, ncclDouble, q, T.comm[i], xs(i));
+        }
+      } else if (x == X_EDGE) {
         const ModeBlock mb = mode_block(c, blk);
         r = T.nc->AllGather(c.edge_local + mb.local_off, c.edge_all + mb.all_off, mb.doubles, ncclDouble, T.comm[i], xs(i));
       } else {
@@ -570,6 +589,7 @@ static int team_make_streams(Team& T) {
   // EKPNP_COMM_CUS_STRICT=1 also confines the comm stream to exactly those CUs.
   // Both, and EKPNP_INLINE_EXCHANGES, are read when the team is made; ekpnp_tune / ekpnp_group_tune change them on a live one.
   T.inline_x = !(std::getenv("EKPNP_INLINE_EXCHANGES") && std::atoi(std::getenv("EKPNP_INLINE_EXCHANGES")) == 0);
+  T.edge_p2p = std::getenv("EKPNP_EDGE_P2P") && std::atoi(std::getenv("EKPNP_EDGE_P2P")) == 1;
   T.comm_cus = std::getenv("EKPNP_COMM_CUS") ? std::atoi(std::getenv("EKPNP_COMM_CUS")) : 0;
   T.comm_strict = std::getenv("EKPNP_COMM_CUS_STRICT") != nullptr && std::atoi(std::getenv("EKPNP_COMM_CUS_STRICT")) != 0;
   const int comm_cus = T.comm_cus;
@@ -693,6 +713,12 @@ static int team_tune(Team& T, const char* knob, int value) {
     const int rc = team_synchronize(T);
     if (rc) return rc;
     T.inline_x = value != 0;
+    return EKPNP_OK;
+  }
+  if (std::strcmp(knob, "edge_p2p") == 0 && (value == 0 || value == 1)) {
+    const int rc = team_synchronize(T);
+    if (rc) return rc;
+    T.edge_p2p = value != 0;
     return EKPNP_OK;
   }
   if (std::strcmp(knob, "comm_cus") == 0 && value >= 0 && value <= 64) return team_set_comm_cus(T, value);
@@ -1106,7 +1132,7 @@ extern "C" int ekpnp_group_step(ekpnp_group* g, int nsteps) { NEEDLIVEGROUP(g); 
 extern "C" int ekpnp_group_tune(ekpnp_group* g, const char* knob, int value) {
   NEEDLIVEGROUP(g);
   if (!knob) { T.err = "knob is NULL"; return EKPNP_ERR_INVALID; }
-  if (std::strcmp(knob, "inline_exchanges") == 0 || std::strcmp(knob, "comm_cus") == 0) return group_fail(T, team_tune(T, knob, value));
+  if (std::strcmp(knob, "inline_exchanges") == 0 || std::strcmp(knob, "comm_cus") == 0 || std::strcmp(knob, "edge_p2p") == 0) return group_fail(T, team_tune(T, knob, value));
   for (size_t i = 0; i < T.m.size(); ++i) {  // a per-slab knob: the same on every slab (an invalid one is refused by the first, nothing changed)
     int rc = use(T, (int)i);
     if (rc) return rc;

@@ -308,6 +308,10 @@ int ekpnp_copy_bandwidth(ekpnp_ctx* ctx, size_t bytes, double* gb_per_s);
  *     of block k-1 on the comm stream, stage 2 of block k as soon as its edge values are there.  The edge buffers are then
  *     laid out block by block, which only the library's own transport exchanges: ekpnp_poisson_stage1/2 refuse such a
  *     context.  phi is bit-identical for every value.
+ *   "edge_p2p" (EKPNP_EDGE_P2P, default 0): the EDGE all-gather of an RCCL transport as one direct ncclSend / ncclRecv pair
+ *     with every peer (plus a device copy of the rank's own piece) instead of ncclAllGather: on xGMI every peer is one hop
+ *     away on a link of its own, so a rank's piece leaves on all links at once.  The pieces land where the all-gather puts
+ *     them: same bits.  Which of the two is faster between devices only a multi-GPU run can say (a `comm_ab` leg).
  * bench.py runs a few steps under each of these after its timed region on N > 1 GPUs (`comm_ab`). */
 int ekpnp_tune(ekpnp_ctx* ctx, const char* knob, int value);
 /* Every kernel launch of the library is checked: a rejected launch makes the entry point return

@@ -288,9 +288,9 @@ def test_comm_ab_leg_keys_and_restoration():
     assert leg["knob"] == "edge_chunks=4" and leg["collide_bulk_ms"] == 39.0 and leg["edge_wait_ms"] == 0.4 and leg["stage2_ms"] == 1.1
     # the legs cover every knob the verdict names, and every knob of a leg has a default to go back to
     knobs = {k for _, ks in b.COMM_AB_LEGS for k, _ in ks}
-    assert knobs == {"inline_exchanges", "comm_cus", "lead_planes", "edge_chunks"} and knobs <= set(b.AB_DEFAULTS)
+    assert knobs == {"inline_exchanges", "comm_cus", "lead_planes", "edge_chunks", "edge_p2p"} and knobs <= set(b.AB_DEFAULTS)
     assert b.COMM_AB_LEGS[0] == ("defaults", [])
-    assert b.ab_baseline() == {"inline_exchanges": 1, "comm_cus": 0, "lead_planes": 2, "edge_chunks": 1}
+    assert b.ab_baseline() == {"inline_exchanges": 1, "comm_cus": 0, "lead_planes": 2, "edge_chunks": 1, "edge_p2p": 0}
     mm = b.min_max_by_rank([{"collide_bulk": 38.7, "poisson": 2.1, "rest": 0.3}, {"collide_bulk": 38.9, "poisson": 2.6, "rest": 0.2}])
     assert mm == {"min": {"collide_bulk": 38.7, "poisson": 2.1, "rest": 0.2}, "max": {"collide_bulk": 38.9, "poisson": 2.6, "rest": 0.3}}
     src = open(os.path.join(ROOT, "bench.py")).read()
@@ -321,19 +321,19 @@ def test_comm_ab_legs_agree_over_two_gloo_ranks(tmp_path):
     assert [x["rank"] for x in ranks] == [0, 1]
     for x in ranks:
         legs = {l["knob"]: l for l in x["legs"]}
-        assert set(legs) == {"defaults", "inline_exchanges=0", "comm_cus=8", "lead_planes=0", "edge_chunks=4", "edge_chunks=4 comm_cus=8"}
+        assert set(legs) == {"defaults", "inline_exchanges=0", "comm_cus=8", "lead_planes=0", "edge_chunks=4", "edge_chunks=4 comm_cus=8", "edge_p2p=1"}
         assert "error" in legs["comm_cus=8"] and "error" in legs["edge_chunks=4 comm_cus=8"]
         assert ("refused on another rank" in legs["comm_cus=8"]["error"]) == (x["rank"] == 0)
-        for k in ("defaults", "inline_exchanges=0", "lead_planes=0", "edge_chunks=4"):
+        for k in ("defaults", "inline_exchanges=0", "lead_planes=0", "edge_chunks=4", "edge_p2p=1"):
             # maxima over the ranks: rank 1's sweep (200 ms / 10 steps), waits (2 ms / 10) and EDGE stage (4 ms / 10 solves)
             assert legs[k]["collide_bulk_ms"] == 20.0 and legs[k]["halo_wait_ms"] == 0.2 and legs[k]["edge_exchange_ms"] == 0.4, legs[k]
         steps = [c for c in x["calls"] if c[0] == "step"]
-        assert len(steps) == 2 * 4  # (2 settling + 10 timed) for the four legs that ran, none for the refused ones
+        assert len(steps) == 2 * 5  # (2 settling + 10 timed) for the five legs that ran, none for the refused ones
         tunes = [c for c in x["calls"] if c[0] == "tune"]
         final = {}
         for _, k, v in tunes:
             final[k] = v
-        assert final == {"inline_exchanges": 1, "comm_cus": 0, "lead_planes": 2, "edge_chunks": 1}
+        assert final == {"inline_exchanges": 1, "comm_cus": 0, "lead_planes": 2, "edge_chunks": 1, "edge_p2p": 0}
 
 
 def test_headline_guard_prints_the_measured_line_when_a_later_leg_hangs(tmp_path):

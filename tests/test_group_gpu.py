@@ -807,7 +807,8 @@ def test_transport_knobs_on_a_live_one_rank_ring(pkg, O):
     want, comm0 = run([])
     assert comm0["edge"]["n"] == 4 and comm0["halo"]["n"] == 4 and comm0["phi"]["n"] == 4
     for settings in ([("inline_exchanges", 0)], [("comm_cus", 8)], [("comm_cus", 8), ("comm_cus", 0)], [("lead_planes", 0)], [("merged_faces", 0)],
-                     [("edge_chunks", 4)], [("inline_exchanges", 0), ("edge_chunks", 2), ("comm_cus", 16), ("lead_planes", 3)]):
+                     [("edge_chunks", 4)], [("edge_p2p", 1)], [("edge_p2p", 1), ("edge_chunks", 2)],
+                     [("inline_exchanges", 0), ("edge_chunks", 2), ("comm_cus", 16), ("lead_planes", 3)]):
         got, comm = run(settings)
         for k in want:
             assert np.array_equal(got[k], want[k]), (settings, k)

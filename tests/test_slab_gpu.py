@@ -188,10 +188,11 @@ def test_native_rccl_ranks_sharing_one_gpu(pkg, O, tmp_path, shape, nprocs, in_p
                OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if nprocs == 3:  # the three-rank case takes the A/B partner of k_collide_faces: a launch per face (k_collide_wall, k_collide_edge)
         env["EKPNP_MERGED_FACES"] = "0"
+        env["EKPNP_EDGE_P2P"] = "1"  # ... and gathers the edge values with direct send / receive pairs (two peers per rank) from the first solve on
     if nprocs == 4:  # round 5: the four-rank case gathers the edge values in 3 pipelined mode blocks from the first solve on (nxh = 24)
         env["EKPNP_EDGE_CHUNKS"] = "3"
     if nprocs == 2:  # ... and the two-rank case turns the transport's knobs on the live communicator after half of the steps
-        env["EKPNP_RCCL_TUNE_MIDWAY"] = "inline_exchanges=0,edge_chunks=2,lead_planes=0,comm_cus=8"
+        env["EKPNP_RCCL_TUNE_MIDWAY"] = "inline_exchanges=0,edge_chunks=2,lead_planes=0,comm_cus=8,edge_p2p=1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nprocs}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rccl_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)

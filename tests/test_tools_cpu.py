@@ -70,3 +70,67 @@ def test_committed_round5_overlap_profiles_are_not_empty():
     for f in files:
         d = json.load(open(os.path.join(prof, f)))
         assert d["steps_seen"] >= 5 and d["summary"]["hidden"] is True, f
+
+
+def test_summarize_profile_arithmetic_on_a_synthetic_profile_directory(tmp_path):
+    """tools/summarize_profile.py turns the raw --pmc passes into roofline.traffic and config.step_traffic_bytes.  On a made-up
+    profile directory with known numbers: FETCH_SIZE is corrected by the factor the calibration copy yields (2.0 on gfx950: the
+    counter tallies 128-byte requests at 64), the mean is over a kernel's LARGEST launches only (the bench runs the same kernels
+    on a small replica for its start state), the steady-state sweep is the PULL = true instantiation, and a step's table holds
+    the kernels between the last two launches of the sweep times their counter bytes."""
+    import summarize_profile as sp
+
+    src, dst = tmp_path / "prof", tmp_path / "out"
+    for d in ("trace", "calib_fetch", "calib_write", "pmc_fetch", "pmc_write"):
+        (src / d).mkdir(parents=True)
+    (src / "trace" / "trace_kernel_stats.csv").write_text('"Name","Calls"\n"x",1\n')
+    true_kib = (1 << 30) * 8 / 1024
+
+    def pmc(path, rows):
+        with open(path, "w") as f:
+            f.write('"Kernel_Name","Grid_Size","Counter_Value"\n')
+            for name, grid, val in rows:
+                f.write(f'"{name}",{grid},{val}\n')
+
+    copy8, shift = "k_copy8(double const*, double*, unsigned long)", "k_copy8_shift(double const*, double*, unsigned long)"
+    pmc(src / "calib_fetch" / "pmc_counter_collection.csv", [(copy8, 1000, true_kib / 2), (shift, 1000, true_kib * 0.75)])
+    pmc(src / "calib_write" / "pmc_counter_collection.csv", [(copy8, 1000, true_kib), (shift, 1000, true_kib)])
+    sweep = "void ekpnp::k_collide_bulk<4, true, true>(ekpnp::KArgs, int, int, int, int)"
+    first = "void ekpnp::k_collide_bulk<4, false, true>(ekpnp::KArgs, int, int, int, int)"
+    wall, tri = "void ekpnp::k_collide_wall<4, true, true>(ekpnp::KArgs)", "void ekpnp::k_tridiag_part<8, 64, 8>(ekpnp::PArgs)"
+    # sweep: two big launches (mean 100 and 200 KiB raw) and a replica launch that must not count
+    pmc(src / "pmc_fetch" / "pmc_counter_collection.csv", [(sweep, 64, 1.0), (sweep, 4096, 90.0), (sweep, 4096, 110.0), (first, 4096, 95.0), (wall, 128, 3.0), (tri, 256, 10.0)])
+    pmc(src / "pmc_write" / "pmc_counter_collection.csv", [(sweep, 64, 1.0), (sweep, 4096, 200.0), (sweep, 4096, 200.0), (first, 4096, 200.0), (wall, 128, 2.0), (tri, 256, 11.0)])
+    with open(src / "trace" / "trace_kernel_trace.csv", "w") as f:
+        f.write('"Stream_Id","Kernel_Name","Start_Timestamp","End_Timestamp","Workgroup_Size_X","Grid_Size_X"\n')
+        t = 0
+        for name, gx in [(first, 4096), (wall, 128), (tri, 256), (sweep, 64), (sweep, 4096), (wall, 128), (tri, 256), (tri, 256), (tri, 256), ("k_not_profiled()", 8), (sweep, 4096), (wall, 128)]:
+            f.write(f'"1","{name}",{t},{t + 5},64,{gx}\n')
+            t += 10
+    (dst).mkdir()
+    json.dump({"cfg2": {"kernel": "kept", "hbm_bytes_per_launch": 1.0}}, open(dst / "pmc_traffic.json", "w"))
+    out, bulk, rec = sp.summarize("rXX", "cfg3", str(src), str(dst))
+    assert out["calibration"]["fetch_factor"] == 2.0 and out["calibration"]["write_factor"] == 1.0
+    assert out["calibration"]["misaligned_by_one_element_fetch_ratio"] == 1.5
+    assert bulk == sweep
+    assert out["kernels"][sweep]["hbm_read_bytes"] == 100.0 * 1024 * 2.0 and out["kernels"][sweep]["hbm_write_bytes"] == 200.0 * 1024
+    assert rec["hbm_bytes_per_launch"] == 400.0 * 1024 and rec["round"] == "rXX"
+    table = {e["kernel"]: e for e in rec["step"]["kernels"]}
+    assert set(table) == {sweep, wall, tri, "k_not_profiled()"}  # the kernels from the second-to-last big sweep launch up to the last
+    assert table[tri]["launches_per_step"] == 3 and table[tri]["hbm_bytes_per_launch"] == (10.0 * 2.0 + 11.0) * 1024
+    assert rec["step"]["kernels_without_counters"] == ["k_not_profiled()"]
+    assert rec["step"]["hbm_bytes_per_step"] == (400.0 + (3.0 * 2 + 2.0) + 3 * (10.0 * 2 + 11.0)) * 1024
+    written = json.load(open(dst / "pmc_traffic.json"))
+    assert written["cfg2"]["kernel"] == "kept" and written["cfg3"]["kernel"] == sweep  # other workloads' records stay
+    assert os.path.exists(dst / "rXX_cfg3_pmc_summary.json") and os.path.exists(dst / "rXX_cfg3_kernel_stats.csv")
+    # bench.py reads the record the same way: a step with a kernel that has no counters yields no step total
+    sys.path.insert(0, ROOT)
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module_for_traffic", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.step_traffic_of(rec) is None
+    rec["step"]["kernels"] = [e for e in rec["step"]["kernels"] if e["hbm_bytes_per_launch"] is not None]
+    rec["step"]["kernels_without_counters"] = []
+    assert b.step_traffic_of(rec) == (400.0 + 8.0 + 93.0) * 1024
